@@ -1,0 +1,508 @@
+// Fused volumetric ray march for gfx950 -- the MI355X-native pipeline behind
+// DirectVoxGO.forward (/root/reference/lib/dvgo.py:450-577) and its backward.
+//
+// The reference runs ~20 kernels with 5 host syncs and materialises every intermediate
+// (ray_pts, int64 ids, masks, four boolean compactions).  Here the path is four kernels:
+//
+//   march_density   one wavefront per ray, lanes = 64 consecutive steps:
+//                   position -> bbox test -> occupancy byte -> density trilinear -> alpha ->
+//                   alpha filter -> wave product-scan of (1-alpha) with ballot early stop ->
+//                   weight filter -> ballot/popcount compaction into per-ray scratch records
+//   (scan of the per-ray survivor counts, one workgroup)
+//   march_gather    flat over the surviving samples in the reference's (ray, step) order:
+//                   feature-grid trilinear (16-byte channel vectors) + final ids/weights
+//   march_composite one wavefront per ray: weighted colour/depth sum + background
+//
+// and the backward mirrors it (composite_bwd, feat_bwd, density_bwd).  Filter order is the
+// reference's: mask -> alpha > thres (before transmittance) -> T < 1e-3 stop -> weight > thres.
+#include "common.h"
+
+__device__ __forceinline__ unsigned long long lanemask_lt(int lane) {
+  return (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+}
+
+// inclusive product scan across the wave
+__device__ __forceinline__ float wave_prod_scan(float v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const float o = __shfl_up(v, d);
+    if (lane >= d) v *= o;
+  }
+  return v;
+}
+
+// exclusive suffix sum across the wave: sum of v over lanes > lane
+__device__ __forceinline__ float wave_suffix_excl(float v, int lane, float& total) {
+  float inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const float o = __shfl_down(inc, d);
+    if (lane + d < 64) inc += o;
+  }
+  total = dvgo_readlane_f(inc, 0);
+  float ex = __shfl_down(inc, 1);
+  if (lane == 63) ex = 0.0f;
+  return ex;
+}
+
+// Scratch records of ray r start at cum[r]-n_steps[r] (exact, ray-major M0 layout) when the
+// inclusive cumsum is given, else at r*rec_stride (fixed stride = an upper bound of n_steps,
+// which saves the scan and the host read of M0).
+__device__ __forceinline__ int64_t rec_base(const int64_t* __restrict__ cum, const int64_t* __restrict__ n_steps,
+                                            int64_t rec_stride, int64_t ray) {
+  return cum ? (cum[ray] - n_steps[ray]) : ray * rec_stride;
+}
+
+struct MarchParams {
+  float mnx, mny, mnz, mxx, mxy, mxz;
+  float stepdist;
+  float scx, scy, scz, shx, shy, shz;   // xyz2ijk scale / shift
+  int mX, mY, mZ;
+  int X, Y, Z;
+  float act_shift, interval, thres;
+};
+
+__global__ void __launch_bounds__(DVGO_BLOCK)
+march_density_kernel(const float* __restrict__ rays_start, const float* __restrict__ rays_dir,
+                     const int64_t* __restrict__ n_steps, const int64_t* __restrict__ cum,
+                     int64_t rec_stride, int64_t n_rays, const uint8_t* __restrict__ mask,
+                     const float* __restrict__ density, MarchParams P,
+                     dvgo_rec2_t* __restrict__ rec2, dvgo_rec3_t* __restrict__ rec3,
+                     int32_t* __restrict__ n2, int32_t* __restrict__ n3,
+                     float* __restrict__ alphainv_last) {
+  const int64_t ray = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (ray >= n_rays) return;
+  const int ns = __builtin_amdgcn_readfirstlane((int)n_steps[ray]);
+  const int64_t cs0 = rec_base(cum, n_steps, rec_stride, ray);
+  const float sx = rays_start[3 * ray], sy = rays_start[3 * ray + 1], sz = rays_start[3 * ray + 2];
+  const float dx = rays_dir[3 * ray], dy = rays_dir[3 * ray + 1], dz = rays_dir[3 * ray + 2];
+  const int64_t YZ = (int64_t)P.Y * P.Z;
+  const bool filt = P.thres > 0.0f;
+
+  float Tc = 1.0f;
+  int c2 = 0, c3 = 0;
+  for (int base = 0; base < ns; base += 64) {
+    const int step = base + lane;
+    const bool act = step < ns;
+    const float dist = P.stepdist * (float)step;
+    const float px = fmaf(dx, dist, sx), py = fmaf(dy, dist, sy), pz = fmaf(dz, dist, sz);
+    bool keep = act && !((P.mnx > px) | (P.mny > py) | (P.mnz > pz) | (P.mxx < px) | (P.mxy < py) | (P.mxz < pz));
+    if (mask != nullptr && keep) {
+      const int i = (int)roundf(fmaf(px, P.scx, P.shx));
+      const int j = (int)roundf(fmaf(py, P.scy, P.shy));
+      const int k = (int)roundf(fmaf(pz, P.scz, P.shz));
+      keep = (0 <= i) & (i < P.mX) & (0 <= j) & (j < P.mY) & (0 <= k) & (k < P.mZ);
+      if (keep) keep = mask[((int64_t)i * P.mY + j) * P.mZ + k] != 0;
+    }
+    float e = 0.f, a = 0.f;
+    if (keep) {
+      const TriSetup t = dvgo_tri_setup(px, py, pz, P.mnx, P.mny, P.mnz, P.mxx, P.mxy, P.mxz, P.X, P.Y, P.Z);
+      float d = 0.f;
+#pragma unroll
+      for (int n = 0; n < 8; ++n) {
+        if (dvgo_tri_inb(t, n, P.X, P.Y, P.Z)) {
+          const int64_t off = (int64_t)(t.i0 + ((n >> 2) & 1)) * YZ + (int64_t)(t.j0 + ((n >> 1) & 1)) * P.Z +
+                              (t.k0 + (n & 1));
+          d = fmaf(density[off], dvgo_tri_weight(t, n), d);
+        }
+      }
+      e = expf(d + P.act_shift);
+      a = 1.0f - powf(1.0f + e, -P.interval);
+      if (filt) keep = a > P.thres;
+    }
+    // transmittance: T_before[lane] = Tc * prod_{l<lane} f_l, f = 1 - alpha + 1e-10 for kept samples
+    const float f = keep ? (float)(1.0 - (double)a + 1e-10) : 1.0f;
+    const float pincl = wave_prod_scan(f, lane);
+    float pexcl = __shfl_up(pincl, 1);
+    if (lane == 0) pexcl = 1.0f;
+    const float T_before = Tc * pexcl;
+    const float T_after = Tc * pincl;
+    const unsigned long long stop = __ballot(keep && ((double)T_after < 1e-3));
+    const int first = stop ? (__ffsll((long long)stop) - 1) : 63;
+    const bool valid2 = keep && (lane <= first);
+    const float w = T_before * a;
+    const bool keep3 = valid2 && (!filt || (w > P.thres));
+    const unsigned long long m2 = __ballot(valid2), m3 = __ballot(keep3);
+    const unsigned long long lt = lanemask_lt(lane);
+    if (valid2) {
+      dvgo_rec2_t r;
+      r.step = step | (keep3 ? (int32_t)0x80000000 : 0);
+      r.exp_d = e; r.alpha = a; r.T = T_before;
+      rec2[cs0 + c2 + __popcll(m2 & lt)] = r;
+    }
+    if (keep3) {
+      dvgo_rec3_t r;
+      r.step = step; r.weight = w; r.alpha = a; r.j2 = c2 + __popcll(m2 & lt);
+      rec3[cs0 + c3 + __popcll(m3 & lt)] = r;
+    }
+    c2 += __popcll(m2);
+    c3 += __popcll(m3);
+    Tc = dvgo_readlane_f(T_after, first);
+    if (stop) break;
+  }
+  if (lane == 0) {
+    n2[ray] = c2;
+    n3[ray] = c3;
+    alphainv_last[ray] = Tc;
+  }
+}
+
+// ----------------------------------------------------------------------------------
+// march_gather: flat over M3.  C4 = C/4 channel vectors when the grid is channels-last.
+// ----------------------------------------------------------------------------------
+template <int CVEC>   // CVEC > 0: channels-last, C == 4*CVEC, 16-B aligned ; 0: generic strides
+__global__ void __launch_bounds__(DVGO_BLOCK)
+march_gather_kernel(const dvgo_rec3_t* __restrict__ rec3, const int64_t* __restrict__ n_steps,
+                    const int64_t* __restrict__ cum, int64_t rec_stride, const int64_t* __restrict__ off3,
+                    int64_t n_rays, int64_t M3, const float* __restrict__ rays_start, const float* __restrict__ rays_dir,
+                    MarchParams P, const float* __restrict__ k0, int C, int64_t sC, int64_t sX,
+                    int64_t sY, int64_t sZ, int64_t* __restrict__ ray_id, int64_t* __restrict__ step_id,
+                    float* __restrict__ weights, float* __restrict__ alpha, float* __restrict__ feat) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M3) return;
+  const int64_t r = dvgo_upper_bound(off3 + 1, n_rays, i);   // off3[r] <= i < off3[r+1]
+  const int64_t k = i - off3[r];
+  const dvgo_rec3_t rec = rec3[rec_base(cum, n_steps, rec_stride, r) + k];
+  ray_id[i] = r;
+  step_id[i] = rec.step;
+  weights[i] = rec.weight;
+  alpha[i] = rec.alpha;
+  float px, py, pz;
+  dvgo_sample_pos(rays_start, rays_dir, r, P.stepdist, rec.step, px, py, pz);
+  const TriSetup t = dvgo_tri_setup(px, py, pz, P.mnx, P.mny, P.mnz, P.mxx, P.mxy, P.mxz, P.X, P.Y, P.Z);
+  float w[8];
+  int64_t off[8];
+  bool ok[8];
+#pragma unroll
+  for (int n = 0; n < 8; ++n) {
+    w[n] = dvgo_tri_weight(t, n);
+    ok[n] = dvgo_tri_inb(t, n, P.X, P.Y, P.Z);
+    off[n] = (int64_t)(t.i0 + ((n >> 2) & 1)) * sX + (int64_t)(t.j0 + ((n >> 1) & 1)) * sY +
+             (int64_t)(t.k0 + (n & 1)) * sZ;
+  }
+  if (CVEC > 0) {
+    float4 acc[CVEC > 0 ? CVEC : 1];
+#pragma unroll
+    for (int c = 0; c < CVEC; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+      if (ok[n]) {
+        const float4* p = reinterpret_cast<const float4*>(k0 + off[n]);
+#pragma unroll
+        for (int c = 0; c < CVEC; ++c) {
+          const float4 v = p[c];
+          acc[c].x = fmaf(v.x, w[n], acc[c].x);
+          acc[c].y = fmaf(v.y, w[n], acc[c].y);
+          acc[c].z = fmaf(v.z, w[n], acc[c].z);
+          acc[c].w = fmaf(v.w, w[n], acc[c].w);
+        }
+      }
+    }
+    float4* o = reinterpret_cast<float4*>(feat + i * (int64_t)(4 * CVEC));
+#pragma unroll
+    for (int c = 0; c < CVEC; ++c) o[c] = acc[c];
+  } else {
+    for (int c = 0; c < C; ++c) {
+      float acc = 0.f;
+#pragma unroll
+      for (int n = 0; n < 8; ++n)
+        if (ok[n]) acc = fmaf(k0[c * sC + off[n]], w[n], acc);
+      feat[i * C + c] = acc;
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------
+// march_composite: one wavefront per ray over [off3[r], off3[r+1]).
+// ----------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+  return v;
+}
+
+__global__ void __launch_bounds__(DVGO_BLOCK)
+march_composite_kernel(const float* __restrict__ weights, const float* __restrict__ rgb,
+                       const int64_t* __restrict__ step_id, const int64_t* __restrict__ off3,
+                       int64_t n_rays, const float* __restrict__ alphainv_last, float bg,
+                       float* __restrict__ rgb_marched, float* __restrict__ depth) {
+  const int64_t ray = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (ray >= n_rays) return;
+  const int64_t b = off3[ray], e = off3[ray + 1];
+  float r = 0.f, g = 0.f, bl = 0.f, dsum = 0.f;
+  for (int64_t i = b + lane; i < e; i += 64) {
+    const float w = weights[i];
+    r = fmaf(w, rgb[3 * i + 0], r);
+    g = fmaf(w, rgb[3 * i + 1], g);
+    bl = fmaf(w, rgb[3 * i + 2], bl);
+    if (depth) dsum = fmaf(w, (float)step_id[i], dsum);
+  }
+  r = wave_sum(r); g = wave_sum(g); bl = wave_sum(bl);
+  if (depth) dsum = wave_sum(dsum);
+  if (lane == 0) {
+    const float last = alphainv_last[ray] * bg;
+    rgb_marched[3 * ray + 0] = r + last;
+    rgb_marched[3 * ray + 1] = g + last;
+    rgb_marched[3 * ray + 2] = bl + last;
+    if (depth) depth[ray] = dsum;
+  }
+}
+
+__global__ void __launch_bounds__(DVGO_BLOCK)
+march_composite_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ weights,
+                           const float* __restrict__ rgb, const int64_t* __restrict__ ray_id, int64_t M3,
+                           float* __restrict__ grad_weights, float* __restrict__ grad_rgb) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M3) return;
+  const int64_t r = ray_id[i];
+  const float g0 = gout[3 * r], g1 = gout[3 * r + 1], g2 = gout[3 * r + 2];
+  const float w = weights[i];
+  if (grad_weights)
+    grad_weights[i] = fmaf(g2, rgb[3 * i + 2], fmaf(g1, rgb[3 * i + 1], g0 * rgb[3 * i]));
+  if (grad_rgb) {
+    grad_rgb[3 * i + 0] = g0 * w;
+    grad_rgb[3 * i + 1] = g1 * w;
+    grad_rgb[3 * i + 2] = g2 * w;
+  }
+}
+
+// ----------------------------------------------------------------------------------
+// march_feat_bwd: thread = (sample, channel); 8 float atomics each.  Channels-last keeps the
+// C channels of a corner on adjacent lanes (contiguous 4*C-byte runs per atomic instruction).
+// ----------------------------------------------------------------------------------
+__global__ void __launch_bounds__(DVGO_BLOCK)
+march_feat_bwd_kernel(const float* __restrict__ grad_feat, const int64_t* __restrict__ ray_id,
+                      const int64_t* __restrict__ step_id, int64_t M3,
+                      const float* __restrict__ rays_start, const float* __restrict__ rays_dir,
+                      MarchParams P, int C, int64_t sC, int64_t sX, int64_t sY, int64_t sZ,
+                      float* __restrict__ grad_k0) {
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= M3 * C) return;
+  const int64_t i = tid / C;
+  const int c = (int)(tid - i * C);
+  float px, py, pz;
+  dvgo_sample_pos(rays_start, rays_dir, ray_id[i], P.stepdist, (int)step_id[i], px, py, pz);
+  const TriSetup t = dvgo_tri_setup(px, py, pz, P.mnx, P.mny, P.mnz, P.mxx, P.mxy, P.mxz, P.X, P.Y, P.Z);
+  const float g = grad_feat[tid];
+#pragma unroll
+  for (int n = 0; n < 8; ++n) {
+    if (!dvgo_tri_inb(t, n, P.X, P.Y, P.Z)) continue;
+    const int64_t off = (int64_t)(t.i0 + ((n >> 2) & 1)) * sX + (int64_t)(t.j0 + ((n >> 1) & 1)) * sY +
+                        (int64_t)(t.k0 + (n & 1)) * sZ;
+    atomicAdd(grad_k0 + c * sC + off, dvgo_tri_weight(t, n) * g);
+  }
+}
+
+// ----------------------------------------------------------------------------------
+// march_density_bwd: one wavefront per ray, rec2 chunks walked from the far end.
+//   K13 (render_utils_kernel.cu:521-530): g_alpha = g_w*T - acc/((1-alpha)+1e-10), acc += g_w*w
+//   K10 (:402-405) raw2alpha backward, then the 8-corner scatter into grad_density.
+// ----------------------------------------------------------------------------------
+__global__ void __launch_bounds__(DVGO_BLOCK)
+march_density_bwd_kernel(const dvgo_rec2_t* __restrict__ rec2, const int32_t* __restrict__ n2,
+                         const int64_t* __restrict__ n_steps, const int64_t* __restrict__ cum,
+                         int64_t rec_stride, const int64_t* __restrict__ off3, int64_t n_rays,
+                         const float* __restrict__ rays_start, const float* __restrict__ rays_dir,
+                         MarchParams P, const float* __restrict__ alphainv_last,
+                         const float* __restrict__ grad_weights, const float* __restrict__ grad_last,
+                         float* __restrict__ grad_density) {
+  const int64_t ray = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (ray >= n_rays) return;
+  const int c2 = __builtin_amdgcn_readfirstlane(n2[ray]);
+  if (c2 == 0) return;
+  const int64_t cs0 = rec_base(cum, n_steps, rec_stride, ray);
+  const int64_t o3 = off3[ray];
+  int c3_rem = (int)(off3[ray + 1] - o3);
+  const float sx = rays_start[3 * ray], sy = rays_start[3 * ray + 1], sz = rays_start[3 * ray + 2];
+  const float dx = rays_dir[3 * ray], dy = rays_dir[3 * ray + 1], dz = rays_dir[3 * ray + 2];
+  const int64_t YZ = (int64_t)P.Y * P.Z;
+  const unsigned long long lt = lanemask_lt(lane);
+  float acc = (grad_last ? grad_last[ray] : 0.0f) * alphainv_last[ray];
+  for (int hi = c2; hi > 0; hi -= 64) {
+    const int lo = max(0, hi - 64);
+    const int n = hi - lo;
+    const bool act = lane < n;
+    dvgo_rec2_t rec;
+    rec.step = 0; rec.exp_d = 0.f; rec.alpha = 0.f; rec.T = 0.f;
+    if (act) rec = rec2[cs0 + lo + lane];
+    const bool flag = act && (rec.step < 0);
+    const int step = rec.step & 0x7fffffff;
+    const unsigned long long m = __ballot(flag);
+    const int cnt = __popcll(m);
+    const int rank = c3_rem - cnt + __popcll(m & lt);
+    c3_rem -= cnt;
+    const float gw = flag ? grad_weights[o3 + rank] : 0.0f;
+    const float w = rec.T * rec.alpha;
+    float total;
+    const float suffix = wave_suffix_excl(gw * w, lane, total);   // inactive lanes contribute 0
+    const float my_acc = acc + suffix;
+    acc += total;
+    if (act) {
+      const float gt = gw * rec.T;
+      const float one_minus = 1.0f - rec.alpha;
+      const float g_alpha = (float)((double)gt - (double)my_acc / ((double)one_minus + 1e-10));
+      double v = fmin((double)rec.exp_d, 1e10) * (double)powf(1.0f + rec.exp_d, -P.interval - 1.0f);
+      v = v * (double)P.interval;
+      v = v * (double)g_alpha;
+      const float g_d = (float)v;
+      const float dist = P.stepdist * (float)step;
+      const float px = fmaf(dx, dist, sx), py = fmaf(dy, dist, sy), pz = fmaf(dz, dist, sz);
+      const TriSetup t = dvgo_tri_setup(px, py, pz, P.mnx, P.mny, P.mnz, P.mxx, P.mxy, P.mxz, P.X, P.Y, P.Z);
+      if (g_d != 0.0f) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          if (!dvgo_tri_inb(t, c, P.X, P.Y, P.Z)) continue;
+          const int64_t off = (int64_t)(t.i0 + ((c >> 2) & 1)) * YZ + (int64_t)(t.j0 + ((c >> 1) & 1)) * P.Z +
+                              (t.k0 + (c & 1));
+          atomicAdd(grad_density + off, dvgo_tri_weight(t, c) * g_d);
+        }
+      }
+    }
+  }
+}
+
+static MarchParams make_params(const float* mn, const float* mx, float stepdist, const float* sc,
+                               const float* sh, int mX, int mY, int mZ, int X, int Y, int Z,
+                               float act_shift, float interval, float thres) {
+  MarchParams P;
+  P.mnx = mn[0]; P.mny = mn[1]; P.mnz = mn[2];
+  P.mxx = mx[0]; P.mxy = mx[1]; P.mxz = mx[2];
+  P.stepdist = stepdist;
+  P.scx = sc ? sc[0] : 0.f; P.scy = sc ? sc[1] : 0.f; P.scz = sc ? sc[2] : 0.f;
+  P.shx = sh ? sh[0] : 0.f; P.shy = sh ? sh[1] : 0.f; P.shz = sh ? sh[2] : 0.f;
+  P.mX = mX; P.mY = mY; P.mZ = mZ;
+  P.X = X; P.Y = Y; P.Z = Z;
+  P.act_shift = act_shift; P.interval = interval; P.thres = thres;
+  return P;
+}
+
+extern "C" {
+
+// NOTE: xyz_min / xyz_max / xyz2ijk_scale / xyz2ijk_shift are HOST pointers (3 floats each)
+// in the fused entry points: they are model constants and travel as kernel arguments.
+
+int dvgo_march_density(const float* rays_start, const float* rays_dir, const int64_t* n_steps,
+                       const int64_t* n_steps_cumsum, int64_t rec_stride, int64_t n_rays, const float* xyz_min,
+                       const float* xyz_max, float stepdist, const uint8_t* mask, int mX, int mY, int mZ,
+                       const float* xyz2ijk_scale, const float* xyz2ijk_shift, const float* density,
+                       int X, int Y, int Z, float act_shift, float interval, float fast_color_thres,
+                       dvgo_rec2_t* rec2, dvgo_rec3_t* rec3, int32_t* n2, int32_t* n3,
+                       float* alphainv_last, void* stream) {
+  if (n_rays < 0 || X <= 0 || Y <= 0 || Z <= 0) return DVGO_EINVAL;
+  if (n_rays == 0) return 0;
+  if (!rays_start || !rays_dir || !n_steps || !xyz_min || !xyz_max || !density ||
+      !rec2 || !rec3 || !n2 || !n3 || !alphainv_last)
+    return DVGO_EINVAL;
+  if (!n_steps_cumsum && rec_stride <= 0) return DVGO_EINVAL;
+  if (mask && (!xyz2ijk_scale || !xyz2ijk_shift || mX <= 0 || mY <= 0 || mZ <= 0)) return DVGO_EINVAL;
+  if (!dvgo_fits(n_rays * 64)) return DVGO_ERANGE;
+  const MarchParams P = make_params(xyz_min, xyz_max, stepdist, xyz2ijk_scale, xyz2ijk_shift, mX, mY, mZ,
+                                    X, Y, Z, act_shift, interval, fast_color_thres);
+  march_density_kernel<<<dvgo_blocks(n_rays * 64, DVGO_BLOCK), DVGO_BLOCK, 0, (hipStream_t)stream>>>(
+      rays_start, rays_dir, n_steps, n_steps_cumsum, rec_stride, n_rays, mask, density, P, rec2, rec3, n2, n3,
+      alphainv_last);
+  DVGO_LAUNCH_CHECK();
+  return 0;
+}
+
+int dvgo_march_gather(const dvgo_rec3_t* rec3, const int64_t* n_steps, const int64_t* n_steps_cumsum,
+                      int64_t rec_stride, const int64_t* off3, int64_t n_rays, int64_t M3, const float* rays_start,
+                      const float* rays_dir, float stepdist, const float* xyz_min, const float* xyz_max,
+                      const float* k0, int C, int X, int Y, int Z, int64_t sC, int64_t sX, int64_t sY,
+                      int64_t sZ, int64_t* ray_id, int64_t* step_id, float* weights, float* alpha,
+                      float* feat, void* stream) {
+  if (n_rays < 0 || M3 < 0 || C < 0 || X <= 0 || Y <= 0 || Z <= 0) return DVGO_EINVAL;
+  if (M3 == 0) return 0;
+  if (!rec3 || !n_steps || !off3 || !rays_start || !rays_dir || !xyz_min || !xyz_max ||
+      !ray_id || !step_id || !weights || !alpha || (C > 0 && (!k0 || !feat)))
+    return DVGO_EINVAL;
+  if (!n_steps_cumsum && rec_stride <= 0) return DVGO_EINVAL;
+  if (!dvgo_fits(M3)) return DVGO_ERANGE;
+  const MarchParams P = make_params(xyz_min, xyz_max, stepdist, nullptr, nullptr, 0, 0, 0, X, Y, Z, 0.f, 0.f, 0.f);
+  hipStream_t s = (hipStream_t)stream;
+  const int blocks = dvgo_blocks(M3, DVGO_BLOCK);
+  const bool vec = (sC == 1) && (C % 4 == 0) && (sX % 4 == 0) && (sY % 4 == 0) && (sZ % 4 == 0) &&
+                   ((((uintptr_t)k0) & 15) == 0) && ((((uintptr_t)feat) & 15) == 0);
+#define DVGO_GATHER(CV)                                                                              \
+  march_gather_kernel<CV><<<blocks, DVGO_BLOCK, 0, s>>>(rec3, n_steps, n_steps_cumsum, rec_stride, off3, \
+      n_rays, M3, rays_start, rays_dir, P, k0, C, sC, sX, sY, sZ, ray_id, step_id, weights, alpha, feat)
+  if (vec && C == 12) DVGO_GATHER(3);
+  else if (vec && C == 4) DVGO_GATHER(1);
+  else if (vec && C == 8) DVGO_GATHER(2);
+  else if (vec && C == 16) DVGO_GATHER(4);
+  else DVGO_GATHER(0);
+#undef DVGO_GATHER
+  DVGO_LAUNCH_CHECK();
+  return 0;
+}
+
+int dvgo_march_composite(const float* weights, const float* rgb, const int64_t* step_id,
+                         const int64_t* off3, int64_t n_rays, const float* alphainv_last, float bg,
+                         float* rgb_marched, float* depth, void* stream) {
+  if (n_rays < 0) return DVGO_EINVAL;
+  if (n_rays == 0) return 0;
+  if (!off3 || !alphainv_last || !rgb_marched) return DVGO_EINVAL;
+  if (depth && !step_id) return DVGO_EINVAL;
+  if (!dvgo_fits(n_rays * 64)) return DVGO_ERANGE;
+  march_composite_kernel<<<dvgo_blocks(n_rays * 64, DVGO_BLOCK), DVGO_BLOCK, 0, (hipStream_t)stream>>>(
+      weights, rgb, step_id, off3, n_rays, alphainv_last, bg, rgb_marched, depth);
+  DVGO_LAUNCH_CHECK();
+  return 0;
+}
+
+int dvgo_march_composite_bwd(const float* grad_rgb_marched, const float* weights, const float* rgb,
+                             const int64_t* ray_id, int64_t M3, int64_t n_rays, float bg,
+                             float* grad_weights, float* grad_rgb, float* grad_last_add, void* stream) {
+  (void)n_rays; (void)bg; (void)grad_last_add;   // grad_last is an N-sized host-side reduction
+  if (M3 < 0) return DVGO_EINVAL;
+  if (M3 == 0) return 0;
+  if (!grad_rgb_marched || !weights || !rgb || !ray_id) return DVGO_EINVAL;
+  if (!dvgo_fits(M3)) return DVGO_ERANGE;
+  march_composite_bwd_kernel<<<dvgo_blocks(M3, DVGO_BLOCK), DVGO_BLOCK, 0, (hipStream_t)stream>>>(
+      grad_rgb_marched, weights, rgb, ray_id, M3, grad_weights, grad_rgb);
+  DVGO_LAUNCH_CHECK();
+  return 0;
+}
+
+int dvgo_march_feat_bwd(const float* grad_feat, const int64_t* ray_id, const int64_t* step_id, int64_t M3,
+                        const float* rays_start, const float* rays_dir, float stepdist,
+                        const float* xyz_min, const float* xyz_max, int C, int X, int Y, int Z,
+                        int64_t sC, int64_t sX, int64_t sY, int64_t sZ, float* grad_k0, void* stream) {
+  if (M3 < 0 || C < 0 || X <= 0 || Y <= 0 || Z <= 0) return DVGO_EINVAL;
+  if (M3 == 0 || C == 0) return 0;
+  if (!grad_feat || !ray_id || !step_id || !rays_start || !rays_dir || !xyz_min || !xyz_max || !grad_k0)
+    return DVGO_EINVAL;
+  if (!dvgo_fits(M3 * C)) return DVGO_ERANGE;
+  const MarchParams P = make_params(xyz_min, xyz_max, stepdist, nullptr, nullptr, 0, 0, 0, X, Y, Z, 0.f, 0.f, 0.f);
+  march_feat_bwd_kernel<<<dvgo_blocks(M3 * C, DVGO_BLOCK), DVGO_BLOCK, 0, (hipStream_t)stream>>>(
+      grad_feat, ray_id, step_id, M3, rays_start, rays_dir, P, C, sC, sX, sY, sZ, grad_k0);
+  DVGO_LAUNCH_CHECK();
+  return 0;
+}
+
+int dvgo_march_density_bwd(const dvgo_rec2_t* rec2, const int32_t* n2, const int64_t* n_steps,
+                           const int64_t* n_steps_cumsum, int64_t rec_stride, const int64_t* off3, int64_t n_rays,
+                           const float* rays_start, const float* rays_dir, float stepdist,
+                           const float* xyz_min, const float* xyz_max, const float* alphainv_last,
+                           float interval, const float* grad_weights, const float* grad_last, int X,
+                           int Y, int Z, float* grad_density, void* stream) {
+  if (n_rays < 0 || X <= 0 || Y <= 0 || Z <= 0) return DVGO_EINVAL;
+  if (n_rays == 0) return 0;
+  if (!rec2 || !n2 || !n_steps || !off3 || !rays_start || !rays_dir || !xyz_min ||
+      !xyz_max || !alphainv_last || !grad_weights || !grad_density)
+    return DVGO_EINVAL;
+  if (!n_steps_cumsum && rec_stride <= 0) return DVGO_EINVAL;
+  if (!dvgo_fits(n_rays * 64)) return DVGO_ERANGE;
+  const MarchParams P = make_params(xyz_min, xyz_max, stepdist, nullptr, nullptr, 0, 0, 0, X, Y, Z, 0.f,
+                                    interval, 0.f);
+  march_density_bwd_kernel<<<dvgo_blocks(n_rays * 64, DVGO_BLOCK), DVGO_BLOCK, 0, (hipStream_t)stream>>>(
+      rec2, n2, n_steps, n_steps_cumsum, rec_stride, off3, n_rays, rays_start, rays_dir, P, alphainv_last,
+      grad_weights, grad_last, grad_density);
+  DVGO_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // extern "C"

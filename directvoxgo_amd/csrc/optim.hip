@@ -1,0 +1,124 @@
+// "next" rows N1/N2 of SURVEY.md section 8f: MaskedAdam updates (K15-K17) and the
+// total-variation gradient (K14).  Pure streaming kernels, HBM bound.
+// Reference semantics: /root/reference/lib/cuda/adam_upd_kernel.cu:8-58,
+//                      /root/reference/lib/cuda/total_variation_kernel.cu:13-35.
+#include "common.h"
+
+template <int MODE>   // 0 plain, 1 masked (skip grad == 0), 2 per-voxel lr
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float perlr,
+                                         float step_size, float beta1, float beta2, float eps) {
+  if (MODE == 1 && g == 0.0f) return;
+  m = fmaf(beta1, m, (1.0f - beta1) * g);
+  v = fmaf(beta2, v, ((1.0f - beta2) * g) * g);
+  const float ss = (MODE == 2) ? step_size * perlr : step_size;
+  p = p - (ss * m) / (sqrtf(v) + eps);
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(DVGO_BLOCK)
+adam_kernel(float* __restrict__ param, const float* __restrict__ grad, float* __restrict__ exp_avg,
+            float* __restrict__ exp_avg_sq, const float* __restrict__ perlr, int64_t n,
+            float step_size, float beta1, float beta2, float eps, bool vec) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (vec) {
+    const int64_t i = t * 4;
+    if (i + 3 < n) {
+      float4 p = *reinterpret_cast<float4*>(param + i);
+      const float4 g = *reinterpret_cast<const float4*>(grad + i);
+      if (MODE == 1 && g.x == 0.f && g.y == 0.f && g.z == 0.f && g.w == 0.f) return;   // nothing to write
+      float4 m = *reinterpret_cast<float4*>(exp_avg + i);
+      float4 v = *reinterpret_cast<float4*>(exp_avg_sq + i);
+      float4 l = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (MODE == 2) l = *reinterpret_cast<const float4*>(perlr + i);
+      adam_one<MODE>(p.x, g.x, m.x, v.x, l.x, step_size, beta1, beta2, eps);
+      adam_one<MODE>(p.y, g.y, m.y, v.y, l.y, step_size, beta1, beta2, eps);
+      adam_one<MODE>(p.z, g.z, m.z, v.z, l.z, step_size, beta1, beta2, eps);
+      adam_one<MODE>(p.w, g.w, m.w, v.w, l.w, step_size, beta1, beta2, eps);
+      *reinterpret_cast<float4*>(param + i) = p;
+      *reinterpret_cast<float4*>(exp_avg + i) = m;
+      *reinterpret_cast<float4*>(exp_avg_sq + i) = v;
+      return;
+    }
+    for (int64_t k = i; k < n; ++k)
+      adam_one<MODE>(param[k], grad[k], exp_avg[k], exp_avg_sq[k], MODE == 2 ? perlr[k] : 0.f, step_size,
+                     beta1, beta2, eps);
+  } else if (t < n) {
+    adam_one<MODE>(param[t], grad[t], exp_avg[t], exp_avg_sq[t], MODE == 2 ? perlr[t] : 0.f, step_size,
+                   beta1, beta2, eps);
+  }
+}
+
+__device__ __forceinline__ float clamp1(float v) { return fminf(fmaxf(v, -1.f), 1.f); }
+
+// One thread per grid element.  `cl` selects the thread -> element order so that consecutive
+// lanes touch consecutive memory for both layouts.  The i axis uses wz (the reference's own
+// quirk, total_variation_kernel.cu:31-32); wx is accepted and unused.
+template <bool DENSE>
+__global__ void __launch_bounds__(DVGO_BLOCK)
+tv_kernel(const float* __restrict__ param, float* __restrict__ grad, float wy, float wz, int64_t C,
+          int64_t I, int64_t J, int64_t K, int64_t sC, int64_t sI, int64_t sJ, int64_t sK, bool cl,
+          int64_t N) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= N) return;
+  int64_t c, i, j, k;
+  if (cl) { c = t % C; k = t / C % K; j = t / C / K % J; i = t / C / K / J; }
+  else    { k = t % K; j = t / K % J; i = t / K / J % I; c = t / K / J / I; }
+  const int64_t o = c * sC + i * sI + j * sJ + k * sK;
+  if (!DENSE && grad[o] == 0.0f) return;
+  const float p = param[o];
+  float g = 0.f;
+  g += (k == 0     ? 0.f : wz * clamp1(p - param[o - sK]));
+  g += (k == K - 1 ? 0.f : wz * clamp1(p - param[o + sK]));
+  g += (j == 0     ? 0.f : wy * clamp1(p - param[o - sJ]));
+  g += (j == J - 1 ? 0.f : wy * clamp1(p - param[o + sJ]));
+  g += (i == 0     ? 0.f : wz * clamp1(p - param[o - sI]));
+  g += (i == I - 1 ? 0.f : wz * clamp1(p - param[o + sI]));
+  grad[o] += g;
+}
+
+extern "C" {
+
+int dvgo_adam_upd(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                  const float* perlr, int64_t n, float step_size, float beta1, float beta2, float eps,
+                  int mode, void* stream) {
+  if (n < 0 || mode < 0 || mode > 2) return DVGO_EINVAL;
+  if (n == 0) return 0;
+  if (!param || !grad || !exp_avg || !exp_avg_sq || (mode == 2 && !perlr)) return DVGO_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const uintptr_t bits = (uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq |
+                         (mode == 2 ? (uintptr_t)perlr : 0);
+  const bool vec = (bits & 15) == 0;
+  const int64_t threads = vec ? (n + 3) / 4 : n;
+  if (!dvgo_fits(threads)) return DVGO_ERANGE;
+  const int blocks = dvgo_blocks(threads, DVGO_BLOCK);
+  if (mode == 0)
+    adam_kernel<0><<<blocks, DVGO_BLOCK, 0, s>>>(param, grad, exp_avg, exp_avg_sq, perlr, n, step_size, beta1, beta2, eps, vec);
+  else if (mode == 1)
+    adam_kernel<1><<<blocks, DVGO_BLOCK, 0, s>>>(param, grad, exp_avg, exp_avg_sq, perlr, n, step_size, beta1, beta2, eps, vec);
+  else
+    adam_kernel<2><<<blocks, DVGO_BLOCK, 0, s>>>(param, grad, exp_avg, exp_avg_sq, perlr, n, step_size, beta1, beta2, eps, vec);
+  DVGO_LAUNCH_CHECK();
+  return 0;
+}
+
+int dvgo_total_variation_add_grad(const float* param, float* grad, float wx, float wy, float wz,
+                                  int64_t C, int64_t sz_i, int64_t sz_j, int64_t sz_k, int64_t sC,
+                                  int64_t sI, int64_t sJ, int64_t sK, int dense_mode, void* stream) {
+  (void)wx;
+  if (C < 0 || sz_i < 0 || sz_j < 0 || sz_k < 0) return DVGO_EINVAL;
+  const int64_t N = C * sz_i * sz_j * sz_k;
+  if (N == 0) return 0;
+  if (!param || !grad) return DVGO_EINVAL;
+  if (!dvgo_fits(N)) return DVGO_ERANGE;
+  wy /= 6; wz /= 6;   // total_variation_kernel.cu:46-48
+  const bool cl = (sC == 1 && C > 1);
+  hipStream_t s = (hipStream_t)stream;
+  if (dense_mode)
+    tv_kernel<true><<<dvgo_blocks(N, DVGO_BLOCK), DVGO_BLOCK, 0, s>>>(param, grad, wy, wz, C, sz_i, sz_j, sz_k, sC, sI, sJ, sK, cl, N);
+  else
+    tv_kernel<false><<<dvgo_blocks(N, DVGO_BLOCK), DVGO_BLOCK, 0, s>>>(param, grad, wy, wz, C, sz_i, sz_j, sz_k, sC, sI, sJ, sK, cl, N);
+  DVGO_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,339 @@
+"""DirectVoxGO scene model, host side, on the MI355X kernels.
+
+Build-side counterpart of /root/reference/lib/dvgo.py:30-577 for the rows of SURVEY.md
+section 8a (H1 sample_ray / hit_coarse_geo, H2 forward): same constructor arguments, same
+``state_dict`` keys ('density', 'k0', 'rgbnet.*', 'mask_cache.*', 'xyz_min', 'xyz_max',
+'viewfreq'), same ``forward(rays_o, rays_d, viewdirs, global_step, **render_kwargs)`` contract and
+result dict, so the training / rendering loops of run.py consume it unchanged.
+
+Two execution paths produce the same dict:
+  fused=True   (default) csrc/march.hip: 4 kernels, 1 host sync per forward;
+  fused=False  the reference's own op-by-op orchestration on the drop-in ops of
+               render_utils.py / ops.py (what a maintainer gets by only swapping the bindings).
+The fork-specific LIIF / positional-encoding experiments of the reference model
+(implicit_voxel_feat, posbase_pe, rgbnet_full_implicit; lib/dvgo.py:40-41,100-122,329-410) are
+outside the north-star path and raise NotImplementedError.
+"""
+import time
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import render_utils as render_utils_hip
+from .fused import MarchConfig, composite, composite_depth, fused_march
+from .ops import Alphas2Weights, MaskCache, Raw2Alpha, grid_sample, segment_coo, total_variation_add_grad
+
+
+def _as_f32(x):
+    return torch.as_tensor(np.asarray(x, dtype=np.float32) if not isinstance(x, torch.Tensor) else x.detach().cpu(),
+                           dtype=torch.float32)
+
+
+def make_rgbnet(dim0, width, depth):
+    """Same module tree (hence state_dict keys) as lib/dvgo.py:123-131."""
+    net = nn.Sequential(
+        nn.Linear(dim0, width), nn.ReLU(inplace=True),
+        *[nn.Sequential(nn.Linear(width, width), nn.ReLU(inplace=True)) for _ in range(depth - 2)],
+        nn.Linear(width, 3))
+    nn.init.constant_(net[-1].bias, 0)
+    return net
+
+
+class DirectVoxGO(nn.Module):
+    def __init__(self, xyz_min, xyz_max, num_voxels=0, num_voxels_base=0, alpha_init=None,
+                 mask_cache_path=None, mask_cache_thres=1e-3, fast_color_thres=0,
+                 rgbnet_dim=0, rgbnet_direct=False, rgbnet_full_implicit=False,
+                 rgbnet_depth=3, rgbnet_width=128, viewbase_pe=4,
+                 posbase_pe=0, implicit_voxel_feat=False,
+                 channels_last=True, fused=True, verbose=False, **kwargs):
+        super().__init__()
+        if posbase_pe > 0 or implicit_voxel_feat or rgbnet_full_implicit:
+            raise NotImplementedError('fork-specific LIIF / posbase_pe / full-implicit variants are out of scope')
+        self.verbose = verbose
+        self.fused = bool(fused)
+        self.channels_last = bool(channels_last)
+        xyz_min, xyz_max = _as_f32(xyz_min), _as_f32(xyz_max)
+        self.register_buffer('xyz_min', xyz_min.clone())
+        self.register_buffer('xyz_max', xyz_max.clone())
+        # host copies: sizing maths runs on the CPU in float32 exactly like the reference's
+        # tensor expressions, and never costs a device sync afterwards
+        self._xyz_min_cpu, self._xyz_max_cpu = xyz_min.clone(), xyz_max.clone()
+        self.fast_color_thres = fast_color_thres
+
+        # lib/dvgo.py:55-62
+        self.num_voxels_base = num_voxels_base
+        self.voxel_size_base = ((self._xyz_max_cpu - self._xyz_min_cpu).prod() / self.num_voxels_base).pow(1 / 3)
+        self.alpha_init = alpha_init
+        self.act_shift = np.log(1 / (1 - alpha_init) - 1)
+        self._set_grid_resolution(num_voxels)
+
+        ws = [int(v) for v in self.world_size]
+        self.density = nn.Parameter(torch.zeros([1, 1, *ws]))
+        self.rgbnet_kwargs = {
+            'rgbnet_dim': rgbnet_dim, 'rgbnet_direct': rgbnet_direct,
+            'rgbnet_full_implicit': rgbnet_full_implicit,
+            'rgbnet_depth': rgbnet_depth, 'rgbnet_width': rgbnet_width, 'viewbase_pe': viewbase_pe,
+        }
+        if rgbnet_dim <= 0:
+            self.k0_dim = 3                 # colour grid, coarse stage (lib/dvgo.py:83-87)
+            self.rgbnet = None
+        else:
+            self.k0_dim = rgbnet_dim        # feature grid + shallow MLP (lib/dvgo.py:88-131)
+            self.rgbnet_direct = rgbnet_direct
+            self.register_buffer('viewfreq', torch.FloatTensor([(2 ** i) for i in range(viewbase_pe)]))
+            dim0 = (3 + 3 * viewbase_pe * 2) + (self.k0_dim if rgbnet_direct else self.k0_dim - 3)
+            self.rgbnet = make_rgbnet(dim0, rgbnet_width, rgbnet_depth)
+        self.k0 = nn.Parameter(self._alloc_k0(ws))
+
+        # occupancy grid (lib/dvgo.py:135-153)
+        self.mask_cache_path = mask_cache_path
+        self.mask_cache_thres = mask_cache_thres
+        if mask_cache_path:
+            coarse = MaskCache(path=mask_cache_path, mask_cache_thres=mask_cache_thres)
+            mask = self._lookup_on_own_grid(coarse, ws)
+        else:
+            mask = torch.ones(ws, dtype=torch.bool)
+        self.mask_cache = MaskCache(path=None, mask=mask, xyz_min=self._xyz_min_cpu, xyz_max=self._xyz_max_cpu)
+        self._cfg_cache = {}
+
+    # ------------------------------------------------------------------ sizing / bookkeeping
+    def _alloc_k0(self, ws, device=None):
+        g = torch.zeros([1, self.k0_dim, *ws], device=device)
+        if self.channels_last and self.k0_dim > 1:
+            g = g.contiguous(memory_format=torch.channels_last_3d)
+        return g
+
+    def _set_grid_resolution(self, num_voxels):
+        """lib/dvgo.py:155-165 (float32 tensor maths on the host)."""
+        self.num_voxels = num_voxels
+        ext = self._xyz_max_cpu - self._xyz_min_cpu
+        self.voxel_size = (ext.prod() / num_voxels).pow(1 / 3)
+        self.world_size = (ext / self.voxel_size).long()
+        self.voxel_size_ratio = self.voxel_size / self.voxel_size_base
+        self._cfg_cache = {}
+        if self.verbose:
+            print('dvgo_amd: world_size', self.world_size.tolist(), 'voxel_size', float(self.voxel_size),
+                  'voxel_size_ratio', float(self.voxel_size_ratio))
+
+    def get_kwargs(self):
+        return {
+            'xyz_min': self._xyz_min_cpu.numpy(), 'xyz_max': self._xyz_max_cpu.numpy(),
+            'num_voxels': self.num_voxels, 'num_voxels_base': self.num_voxels_base,
+            'alpha_init': self.alpha_init, 'act_shift': self.act_shift,
+            'voxel_size_ratio': self.voxel_size_ratio,
+            'mask_cache_path': self.mask_cache_path, 'mask_cache_thres': self.mask_cache_thres,
+            'fast_color_thres': self.fast_color_thres,
+            **self.rgbnet_kwargs,
+        }
+
+    def _grid_xyz(self, ws, device):
+        return torch.stack(torch.meshgrid(
+            torch.linspace(float(self._xyz_min_cpu[0]), float(self._xyz_max_cpu[0]), ws[0], device=device),
+            torch.linspace(float(self._xyz_min_cpu[1]), float(self._xyz_max_cpu[1]), ws[1], device=device),
+            torch.linspace(float(self._xyz_min_cpu[2]), float(self._xyz_max_cpu[2]), ws[2], device=device),
+            indexing='ij'), -1)
+
+    def _lookup_on_own_grid(self, coarse, ws):
+        """Evaluate a coarse MaskCache at this model's voxel centres (lib/dvgo.py:143-148).
+        Needs the GPU (the lookup is a HIP op)."""
+        dev = torch.device('cuda', torch.cuda.current_device())
+        return coarse.to(dev)(self._grid_xyz(ws, dev)).cpu()
+
+    # ------------------------------------------------------------------ grid maintenance (N4)
+    @torch.no_grad()
+    def maskout_near_cam_vox(self, cam_o, near):
+        """lib/dvgo.py:215-226"""
+        ws = list(self.density.shape[2:])
+        xyz = self._grid_xyz(ws, self.density.device)
+        nearest = torch.stack([(xyz.unsqueeze(-2) - co).pow(2).sum(-1).sqrt().amin(-1)
+                               for co in cam_o.to(xyz.device).split(100)]).amin(0)
+        self.density[nearest[None, None] <= near] = -100
+
+    @torch.no_grad()
+    def scale_volume_grid(self, num_voxels):
+        """Progressive up-scaling (lib/dvgo.py:228-263)."""
+        self._set_grid_resolution(num_voxels)
+        ws = tuple(int(v) for v in self.world_size)
+        self.density = nn.Parameter(F.interpolate(self.density.data, size=ws, mode='trilinear', align_corners=True))
+        if self.k0_dim > 0:
+            k0 = F.interpolate(self.k0.data.contiguous(), size=ws, mode='trilinear', align_corners=True)
+            if self.channels_last and self.k0_dim > 1:
+                k0 = k0.contiguous(memory_format=torch.channels_last_3d)
+            self.k0 = nn.Parameter(k0)
+        else:
+            self.k0 = nn.Parameter(self._alloc_k0(ws, device=self.density.device))
+        self_alpha = F.max_pool3d(self.activate_density(self.density), kernel_size=3, padding=1, stride=1)[0, 0]
+        mask = self_alpha > self.fast_color_thres
+        if self.mask_cache_path:
+            coarse = MaskCache(path=self.mask_cache_path, mask_cache_thres=self.mask_cache_thres).to(self.density.device)
+            mask = coarse(self._grid_xyz(ws, self.density.device)) & mask
+        self.mask_cache = MaskCache(path=None, mask=mask.cpu(), xyz_min=self._xyz_min_cpu,
+                                    xyz_max=self._xyz_max_cpu).to(self.density.device)
+        self._cfg_cache = {}
+
+    def voxel_count_views(self, rays_o_tr, rays_d_tr, imsz, near, far, stepsize, downrate=1, irregular_shape=False):
+        """How many views see each voxel (lib/dvgo.py:265-295); drives the per-voxel lr."""
+        eps_time = time.time()
+        N_samples = int(np.linalg.norm(np.array(self.density.shape[2:]) + 1) / stepsize) + 1
+        dev = self.density.device
+        rng = torch.arange(N_samples, device=dev)[None].float()
+        count = torch.zeros_like(self.density.detach())
+        xyz_min, xyz_max = self.xyz_min.to(dev), self.xyz_max.to(dev)
+        voxel_size = float(self.voxel_size)
+        for rays_o_, rays_d_ in zip(rays_o_tr.split(imsz), rays_d_tr.split(imsz)):
+            ones = torch.ones_like(self.density).requires_grad_()
+            if irregular_shape:
+                rays_o_ = rays_o_.split(10000)
+                rays_d_ = rays_d_.split(10000)
+            else:
+                rays_o_ = rays_o_[::downrate, ::downrate].to(dev).flatten(0, -2).split(10000)
+                rays_d_ = rays_d_[::downrate, ::downrate].to(dev).flatten(0, -2).split(10000)
+            for rays_o, rays_d in zip(rays_o_, rays_d_):
+                vec = torch.where(rays_d == 0, torch.full_like(rays_d, 1e-6), rays_d)
+                rate_a = (xyz_max - rays_o) / vec
+                rate_b = (xyz_min - rays_o) / vec
+                t_min = torch.minimum(rate_a, rate_b).amax(-1).clamp(min=near, max=far)
+                step = stepsize * voxel_size * rng
+                interpx = (t_min[..., None] + step / rays_d.norm(dim=-1, keepdim=True))
+                rays_pts = rays_o[..., None, :] + rays_d[..., None, :] * interpx[..., None]
+                self.grid_sampler(rays_pts, ones).sum().backward()
+            with torch.no_grad():
+                count += (ones.grad > 1)
+        if self.verbose:
+            print('dvgo_amd: voxel_count_views', time.time() - eps_time, 's')
+        return count
+
+    def density_total_variation_add_grad(self, weight, dense_mode):
+        """lib/dvgo.py:297-300"""
+        w = weight * float(self.world_size.max()) / 128
+        total_variation_add_grad(self.density, self.density.grad, w, w, w, dense_mode)
+
+    def k0_total_variation_add_grad(self, weight, dense_mode):
+        """lib/dvgo.py:302-305"""
+        w = weight * float(self.world_size.max()) / 128
+        total_variation_add_grad(self.k0, self.k0.grad, w, w, w, dense_mode)
+
+    # ------------------------------------------------------------------ op wrappers
+    def activate_density(self, density, interval=None):
+        """lib/dvgo.py:307-310"""
+        interval = interval if interval is not None else self.voxel_size_ratio
+        shape = density.shape
+        return Raw2Alpha.apply(density.flatten().contiguous(), self.act_shift, interval).reshape(shape)
+
+    def grid_sampler(self, xyz, *grids, **_unused):
+        """lib/dvgo.py:312-328 (bilinear branch)."""
+        ret = [grid_sample(g, xyz, self.xyz_min, self.xyz_max) for g in grids]
+        return ret[0] if len(ret) == 1 else ret
+
+    def hit_coarse_geo(self, rays_o, rays_d, near, far, stepsize, **render_kwargs):
+        """Rays with at least one sample in known-occupied space (lib/dvgo.py:412-423)."""
+        shape = rays_o.shape[:-1]
+        rays_o = rays_o.reshape(-1, 3).contiguous()
+        rays_d = rays_d.reshape(-1, 3).contiguous()
+        stepdist = stepsize * self.voxel_size
+        ray_pts, mask_outbbox, ray_id = render_utils_hip.sample_pts_on_rays(
+            rays_o, rays_d, self.xyz_min, self.xyz_max, near, far, stepdist)[:3]
+        mask_inbbox = ~mask_outbbox
+        hit = torch.zeros([len(rays_o)], dtype=torch.bool, device=rays_o.device)
+        hit[ray_id[mask_inbbox][self.mask_cache(ray_pts[mask_inbbox])]] = 1
+        return hit.reshape(shape)
+
+    def sample_ray(self, rays_o, rays_d, near, far, stepsize, is_train=0, **render_kwargs):
+        """lib/dvgo.py:425-448 -> (ray_pts, ray_id, step_id) of the in-box samples, near to far."""
+        rays_o = rays_o.contiguous()
+        rays_d = rays_d.contiguous()
+        stepdist = stepsize * self.voxel_size
+        ray_pts, mask_outbbox, ray_id, step_id, N_steps, t_min, t_max = render_utils_hip.sample_pts_on_rays(
+            rays_o, rays_d, self.xyz_min, self.xyz_max, near, far, stepdist)
+        mask_inbbox = ~mask_outbbox
+        return ray_pts[mask_inbbox], ray_id[mask_inbbox], step_id[mask_inbbox]
+
+    # ------------------------------------------------------------------ colour head
+    def _shade(self, k0, viewdirs, ray_id):
+        """lib/dvgo.py:512-541 (bilinear / non-implicit branches)."""
+        if self.rgbnet is None:
+            return torch.sigmoid(k0)
+        if self.rgbnet_direct:
+            k0_view = k0
+        else:
+            k0_view = k0[:, 3:]
+            k0_diffuse = k0[:, :3]
+        viewdirs_emb = (viewdirs.unsqueeze(-1) * self.viewfreq).flatten(-2)
+        viewdirs_emb = torch.cat([viewdirs, viewdirs_emb.sin(), viewdirs_emb.cos()], -1)
+        viewdirs_emb = viewdirs_emb.flatten(0, -2)[ray_id]
+        rgb_logit = self.rgbnet(torch.cat([k0_view, viewdirs_emb], -1))
+        if self.rgbnet_direct:
+            return torch.sigmoid(rgb_logit)
+        return torch.sigmoid(rgb_logit + k0_diffuse)
+
+    # ------------------------------------------------------------------ forward (H2)
+    def _march_cfg(self, near, far, stepsize):
+        key = (float(near), float(far), float(stepsize))
+        cfg = self._cfg_cache.get(key)
+        if cfg is None or cfg.mask is not (self.mask_cache.mask if self.mask_cache is not None else None):
+            mc = self.mask_cache
+            cfg = MarchConfig(self.xyz_min, self.xyz_max, stepdist=float(stepsize * self.voxel_size),
+                              act_shift=self.act_shift, interval=float(stepsize * self.voxel_size_ratio),
+                              fast_color_thres=self.fast_color_thres, near=near, far=far,
+                              mask=None if mc is None else mc.mask,
+                              xyz2ijk_scale=None if mc is None else mc.xyz2ijk_scale,
+                              xyz2ijk_shift=None if mc is None else mc.xyz2ijk_shift)
+            self._cfg_cache[key] = cfg
+        return cfg
+
+    def forward(self, rays_o, rays_d, viewdirs, global_step=None, **render_kwargs):
+        """Volume rendering (lib/dvgo.py:450-577).  Returns the reference's dict:
+        alphainv_last [N], weights [M], rgb_marched [N,3], raw_alpha [M], raw_rgb [M,3], ray_id [M]
+        (+ depth [N] when render_kwargs['render_depth'])."""
+        assert len(rays_o.shape) == 2 and rays_o.shape[-1] == 3, 'Only suuport point queries in [N, 3] format'
+        if self.fused:
+            return self._forward_fused(rays_o, rays_d, viewdirs, **render_kwargs)
+        return self._forward_unfused(rays_o, rays_d, viewdirs, global_step, **render_kwargs)
+
+    def _forward_fused(self, rays_o, rays_d, viewdirs, near, far, stepsize, bg, render_depth=False, **_unused):
+        N = len(rays_o)
+        cfg = self._march_cfg(near, far, stepsize)
+        weights, alpha, alphainv_last, k0, ray_id, step_id, off3 = fused_march(
+            self.density, self.k0, rays_o, rays_d, cfg)
+        rgb = self._shade(k0, viewdirs, ray_id)
+        rgb_marched = composite(weights, rgb, alphainv_last, ray_id, off3, bg)
+        ret = {'alphainv_last': alphainv_last, 'weights': weights, 'rgb_marched': rgb_marched,
+               'raw_alpha': alpha, 'raw_rgb': rgb, 'ray_id': ray_id}
+        if render_depth:
+            ret['depth'] = composite_depth(weights.detach(), step_id, off3, N)
+        return ret
+
+    def _forward_unfused(self, rays_o, rays_d, viewdirs, global_step=None, **render_kwargs):
+        """The reference's op sequence (lib/dvgo.py:458-577) on the drop-in ops."""
+        N = len(rays_o)
+        ray_pts, ray_id, step_id = self.sample_ray(rays_o=rays_o, rays_d=rays_d,
+                                                   is_train=global_step is not None, **render_kwargs)
+        interval = render_kwargs['stepsize'] * self.voxel_size_ratio
+        if self.mask_cache is not None:                      # skip known free space
+            mask = self.mask_cache(ray_pts)
+            ray_pts, ray_id, step_id = ray_pts[mask], ray_id[mask], step_id[mask]
+        density = self.grid_sampler(ray_pts, self.density)  # post-activated alpha
+        alpha = self.activate_density(density, interval)
+        if self.fast_color_thres > 0:
+            mask = alpha > self.fast_color_thres
+            ray_pts, ray_id, step_id = ray_pts[mask], ray_id[mask], step_id[mask]
+            alpha = alpha[mask]
+        weights, alphainv_last = Alphas2Weights.apply(alpha, ray_id, N)
+        if self.fast_color_thres > 0:
+            mask = weights > self.fast_color_thres
+            weights, alpha = weights[mask], alpha[mask]
+            ray_pts, ray_id, step_id = ray_pts[mask], ray_id[mask], step_id[mask]
+        k0 = self.grid_sampler(ray_pts, self.k0)
+        rgb = self._shade(k0, viewdirs, ray_id)
+        rgb_marched = segment_coo(src=(weights.unsqueeze(-1) * rgb), index=ray_id,
+                                  out=torch.zeros([N, 3], device=rays_o.device), reduce='sum')
+        rgb_marched = rgb_marched + alphainv_last.unsqueeze(-1) * render_kwargs['bg']
+        ret = {'alphainv_last': alphainv_last, 'weights': weights, 'rgb_marched': rgb_marched,
+               'raw_alpha': alpha, 'raw_rgb': rgb, 'ray_id': ray_id}
+        if render_kwargs.get('render_depth', False):
+            with torch.no_grad():
+                ret['depth'] = segment_coo(src=(weights * step_id), index=ray_id,
+                                           out=torch.zeros([N], device=rays_o.device), reduce='sum')
+        return ret

@@ -1,0 +1,203 @@
+"""Fused ray march: the MI355X-native replacement of the op-by-op pipeline in
+DirectVoxGO.forward (/root/reference/lib/dvgo.py:450-577).
+
+Two autograd Functions wrap the kernels of csrc/march.hip:
+
+  fused_march(...)   sampling + mask + density interp + activation + compositing weights +
+                     both threshold filters + feature interp, returning exactly the tensors the
+                     reference has after its 4th boolean compaction (lib/dvgo.py:488-509);
+                     backward scatters into the density and feature grids.
+  composite(...)     per-ray weighted colour sum + background (lib/dvgo.py:554-559), optional
+                     depth (lib/dvgo.py:569-576).
+
+One host sync per forward (the survivor count M3, needed to size the outputs); the reference
+needs five.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _lib as L
+from ._lib import _flt, _i64, _int, check_f32, check_input, f3, ptr, stream_of
+from .ops import _grid_geom
+
+# scratch budget for fixed-stride records (2 x 16 B per potential sample)
+_MAX_STRIDE_SCRATCH_BYTES = 4 << 30
+
+
+class MarchConfig:
+    """Host-side constants of one model/render setting (model constants travel to the fused
+    kernels as kernel arguments, so they are kept as host arrays here)."""
+
+    def __init__(self, xyz_min, xyz_max, stepdist, act_shift, interval, fast_color_thres, near, far,
+                 mask=None, xyz2ijk_scale=None, xyz2ijk_shift=None):
+        self.xyz_min_t, self.xyz_max_t = xyz_min, xyz_max          # device tensors (prepare kernel)
+        self.xyz_min_h, self.xyz_max_h = f3(xyz_min), f3(xyz_max)  # host copies (fused kernels)
+        self.stepdist = float(stepdist)
+        self.act_shift = float(act_shift)
+        self.interval = float(interval)
+        self.thres = float(fast_color_thres)
+        self.near, self.far = float(near), float(far)
+        self.mask = mask
+        self.scale_h = f3(xyz2ijk_scale) if mask is not None else f3([0, 0, 0])
+        self.shift_h = f3(xyz2ijk_shift) if mask is not None else f3([0, 0, 0])
+
+
+def _rec_stride(cfg, n_rays):
+    """Upper bound of N_steps: t_min,t_max are clamped to [near,far] (render_utils_kernel.cu:32-33)
+    so N_steps <= ceil((far-near)/stepdist) (+1 for the division rounding)."""
+    span = (cfg.far - cfg.near) / cfg.stepdist
+    if not math.isfinite(span) or span < 0:
+        return 0
+    stride = int(math.ceil(span)) + 2
+    if stride * n_rays * 32 > _MAX_STRIDE_SCRATCH_BYTES:
+        return 0
+    return stride
+
+
+class _FusedMarch(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, density, k0, rays_o, rays_d, cfg):
+        for x, n in ((rays_o, 'rays_o'), (rays_d, 'rays_d')):
+            check_input(x, n); check_f32(x, n)
+        if not (density.is_cuda and k0.is_cuda):
+            raise RuntimeError('density must be a CUDA tensor')
+        check_f32(density, 'density'); check_f32(k0, 'k0')
+        if not density.is_contiguous():
+            raise RuntimeError('density must be contiguous')
+        dev = rays_o.device
+        N = rays_o.shape[0]
+        _, X, Y, Z, _, _, _, _ = _grid_geom(density)
+        C, kX, kY, kZ, sC, sX, sY, sZ = _grid_geom(k0)
+        assert (kX, kY, kZ) == (X, Y, Z), 'density and k0 must share world_size'
+        st = stream_of(rays_o)
+        stride = _rec_stride(cfg, N)
+
+        t_min = torch.empty(N, dtype=torch.float32, device=dev)
+        t_max = torch.empty_like(t_min)
+        n_steps = torch.empty(N, dtype=torch.int64, device=dev)
+        start = torch.empty((N, 3), dtype=torch.float32, device=dev)
+        dirs = torch.empty((N, 3), dtype=torch.float32, device=dev)
+        cum = torch.empty(N, dtype=torch.int64, device=dev) if stride == 0 else None
+        n2 = torch.empty(N, dtype=torch.int32, device=dev)
+        n3 = torch.empty(N, dtype=torch.int32, device=dev)
+        last = torch.empty(N, dtype=torch.float32, device=dev)
+        off3 = torch.empty(N + 1, dtype=torch.int64, device=dev)
+        with torch.cuda.device_of(rays_o):
+            L.call('dvgo_sample_pts_prepare', ptr(rays_o), ptr(rays_d), ptr(cfg.xyz_min_t), ptr(cfg.xyz_max_t),
+                   _flt(cfg.near), _flt(cfg.far), _flt(cfg.stepdist), _i64(N), ptr(t_min), ptr(t_max),
+                   ptr(n_steps), ptr(cum), ptr(start), ptr(dirs), st)
+            if stride == 0:
+                cap = int(cum[-1].item()) if N > 0 else 0     # exact layout: one extra host read
+            else:
+                cap = stride * N
+            rec2 = torch.empty((max(cap, 1), 4), dtype=torch.float32, device=dev)
+            rec3 = torch.empty((max(cap, 1), 4), dtype=torch.float32, device=dev)
+            mask = cfg.mask
+            mshape = mask.shape if mask is not None else (0, 0, 0)
+            L.call('dvgo_march_density', ptr(start), ptr(dirs), ptr(n_steps), ptr(cum), _i64(stride), _i64(N),
+                   cfg.xyz_min_h, cfg.xyz_max_h, _flt(cfg.stepdist), ptr(mask), _int(mshape[0]), _int(mshape[1]),
+                   _int(mshape[2]), cfg.scale_h, cfg.shift_h, ptr(density), _int(X), _int(Y), _int(Z),
+                   _flt(cfg.act_shift), _flt(cfg.interval), _flt(cfg.thres), ptr(rec2), ptr(rec3), ptr(n2), ptr(n3),
+                   ptr(last), st)
+            L.call('dvgo_exclusive_scan_i32', ptr(n3), _i64(N), ptr(off3), st)
+            M3 = int(off3[-1].item())                          # the one host sync of the fused forward
+            ray_id = torch.empty(M3, dtype=torch.int64, device=dev)
+            step_id = torch.empty(M3, dtype=torch.int64, device=dev)
+            weights = torch.empty(M3, dtype=torch.float32, device=dev)
+            alpha = torch.empty(M3, dtype=torch.float32, device=dev)
+            feat = torch.empty((M3, C), dtype=torch.float32, device=dev)
+            L.call('dvgo_march_gather', ptr(rec3), ptr(n_steps), ptr(cum), _i64(stride), ptr(off3), _i64(N), _i64(M3),
+                   ptr(start), ptr(dirs), _flt(cfg.stepdist), cfg.xyz_min_h, cfg.xyz_max_h, ptr(k0), _int(C),
+                   _int(X), _int(Y), _int(Z), _i64(sC), _i64(sX), _i64(sY), _i64(sZ), ptr(ray_id), ptr(step_id),
+                   ptr(weights), ptr(alpha), ptr(feat), st)
+        del rec3
+        ctx.cfg = cfg
+        ctx.geom = (X, Y, Z, C, sC, sX, sY, sZ, stride, N)
+        ctx.density_meta, ctx.k0_meta = density, k0
+        ctx.save_for_backward(rec2, n2, n_steps, cum if cum is not None else n_steps, off3, start, dirs, last,
+                              ray_id, step_id)
+        ctx.mark_non_differentiable(alpha, ray_id, step_id, off3)
+        return weights, alpha, last, feat, ray_id, step_id, off3
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_w, _g_alpha, g_last, g_feat, _g_rid, _g_sid, _g_off):
+        rec2, n2, n_steps, cum, off3, start, dirs, last, ray_id, step_id = ctx.saved_tensors
+        X, Y, Z, C, sC, sX, sY, sZ, stride, N = ctx.geom
+        cfg = ctx.cfg
+        cum_p = ptr(cum) if stride == 0 else ptr(None)
+        M3 = ray_id.shape[0]
+        st = stream_of(start)
+        grad_density = grad_k0 = None
+        with torch.cuda.device_of(start):
+            if ctx.needs_input_grad[1] and g_feat is not None and C > 0:
+                grad_k0 = torch.zeros_like(ctx.k0_meta, memory_format=torch.preserve_format)
+                assert grad_k0.stride() == ctx.k0_meta.stride()
+                L.call('dvgo_march_feat_bwd', ptr(g_feat.contiguous()), ptr(ray_id), ptr(step_id), _i64(M3),
+                       ptr(start), ptr(dirs), _flt(cfg.stepdist), cfg.xyz_min_h, cfg.xyz_max_h, _int(C), _int(X),
+                       _int(Y), _int(Z), _i64(sC), _i64(sX), _i64(sY), _i64(sZ), ptr(grad_k0), st)
+            if ctx.needs_input_grad[0]:
+                grad_density = torch.zeros_like(ctx.density_meta)
+                gw = g_w.contiguous() if g_w is not None else torch.zeros(M3, dtype=torch.float32, device=start.device)
+                gl = g_last.contiguous() if g_last is not None else None
+                L.call('dvgo_march_density_bwd', ptr(rec2), ptr(n2), ptr(n_steps), cum_p, _i64(stride), ptr(off3),
+                       _i64(N), ptr(start), ptr(dirs), _flt(cfg.stepdist), cfg.xyz_min_h, cfg.xyz_max_h, ptr(last),
+                       _flt(cfg.interval), ptr(gw), ptr(gl), _int(X), _int(Y), _int(Z), ptr(grad_density), st)
+        return grad_density, grad_k0, None, None, None
+
+
+def fused_march(density, k0, rays_o, rays_d, cfg):
+    """-> weights [M3], raw_alpha [M3], alphainv_last [N], k0 features [M3,C], ray_id, step_id [M3],
+    off3 [N+1] (exclusive offsets of each ray's samples in the M3 arrays)."""
+    return _FusedMarch.apply(density, k0, rays_o.contiguous(), rays_d.contiguous(), cfg)
+
+
+class _Composite(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, weights, rgb, alphainv_last, ray_id, off3, bg):
+        N = alphainv_last.shape[0]
+        rgb = rgb.contiguous()
+        weights = weights.contiguous()
+        out = torch.empty((N, 3), dtype=torch.float32, device=weights.device)
+        with torch.cuda.device_of(weights):
+            L.call('dvgo_march_composite', ptr(weights), ptr(rgb), ptr(None), ptr(off3), _i64(N),
+                   ptr(alphainv_last.contiguous()), _flt(float(bg)), ptr(out), ptr(None), stream_of(weights))
+        ctx.save_for_backward(weights, rgb, ray_id)
+        ctx.bg = float(bg)
+        ctx.N = N
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        weights, rgb, ray_id = ctx.saved_tensors
+        g = g.contiguous()
+        M3 = weights.shape[0]
+        gw = torch.empty_like(weights) if ctx.needs_input_grad[0] else None
+        grgb = torch.empty_like(rgb) if ctx.needs_input_grad[1] else None
+        with torch.cuda.device_of(weights):
+            L.call('dvgo_march_composite_bwd', ptr(g), ptr(weights), ptr(rgb), ptr(ray_id), _i64(M3), _i64(ctx.N),
+                   _flt(ctx.bg), ptr(gw), ptr(grgb), ptr(None), stream_of(weights))
+        glast = g.sum(-1) * ctx.bg if ctx.needs_input_grad[2] else None
+        return gw, grgb, glast, None, None, None
+
+
+def composite(weights, rgb, alphainv_last, ray_id, off3, bg):
+    """rgb_marched = segment_sum(weights * rgb) + alphainv_last * bg   (lib/dvgo.py:554-559)"""
+    return _Composite.apply(weights, rgb, alphainv_last, ray_id, off3, bg)
+
+
+@torch.no_grad()
+def composite_depth(weights, step_id, off3, n_rays):
+    """depth = segment_sum(weights * step_id)   (lib/dvgo.py:569-576, no_grad in the reference)"""
+    dev = weights.device
+    dummy_rgb = torch.zeros((weights.shape[0], 3), dtype=torch.float32, device=dev)
+    zeros = torch.zeros(n_rays, dtype=torch.float32, device=dev)
+    out = torch.empty((n_rays, 3), dtype=torch.float32, device=dev)
+    depth = torch.empty(n_rays, dtype=torch.float32, device=dev)
+    with torch.cuda.device_of(weights):
+        L.call('dvgo_march_composite', ptr(weights.contiguous()), ptr(dummy_rgb), ptr(step_id), ptr(off3),
+               _i64(n_rays), ptr(zeros), _flt(0.0), ptr(out), ptr(depth), stream_of(weights))
+    return depth

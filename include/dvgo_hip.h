@@ -1,0 +1,263 @@
+/*
+ * dvgo_hip.h -- C ABI of libdvgo_hip.so, the MI355X (gfx950) implementation of
+ * DirectVoxGO's volumetric ray-marching hot path.
+ *
+ * This is the drop-in boundary.  The reference binds this path through a pybind11
+ * module (`render_utils_cuda`, /root/reference/lib/cuda/render_utils.cpp:144-155) plus
+ * two third-party calls (torch F.grid_sample, torch_scatter.segment_coo).  Every entry
+ * point below replaces one of those callables; the reference file:line is cited on each.
+ * The ctypes binding a maintainer would add is shown in INTEGRATION.md and implemented in
+ * directvoxgo_amd/_lib.py + directvoxgo_amd/render_utils.py.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless it is
+ *     documented as host; no torch / ATen types.
+ *   - fp32 tensors (`float`), int64 indices (`int64_t`), bool tensors as 1 byte/element
+ *     (`uint8_t`, 0/1) -- the dtypes the reference uses in practice.
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing
+ *     synchronises unless stated.  (The reference uses the legacy default stream and
+ *     the current device; callers here pass torch's current stream.)
+ *   - return value: 0 on success, otherwise the hipError_t of the failed launch /
+ *     a negative DVGO_E* code for invalid arguments.  Empty inputs (0 rays / 0 points)
+ *     are valid everywhere and return 0 without launching.
+ *   - outputs are caller-allocated; sizes are stated per function.
+ */
+#ifndef DVGO_HIP_H
+#define DVGO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DVGO_EINVAL (-1)   /* invalid argument (null pointer, negative size, bad stride) */
+#define DVGO_ERANGE (-2)   /* size exceeds what the kernel's 32-bit indexing supports    */
+
+/* version of this ABI; bumped on any signature change */
+int dvgo_abi_version(void);
+
+/* ---------------------------------------------------------------------------------
+ * Sampling helpers.  render_utils.cpp:44-65 / render_utils_kernel.cu:11-132 (K1-K3)
+ * --------------------------------------------------------------------------------- */
+/* infer_t_minmax(rays_o, rays_d, xyz_min, xyz_max, near, far) -> [t_min, t_max]   [n_rays] each */
+int dvgo_infer_t_minmax(const float* rays_o, const float* rays_d,
+                        const float* xyz_min, const float* xyz_max,
+                        float near, float far, int64_t n_rays,
+                        float* t_min, float* t_max, void* stream);
+
+/* infer_n_samples(t_min, t_max, stepdist) -> n_samples [n_rays] int64 */
+int dvgo_infer_n_samples(const float* t_min, const float* t_max, float stepdist,
+                         int64_t n_rays, int64_t* n_samples, void* stream);
+
+/* infer_ray_start_dir(rays_o, rays_d, t_min) -> [rays_start, rays_dir]   [n_rays,3] each */
+int dvgo_infer_ray_start_dir(const float* rays_o, const float* rays_d, const float* t_min,
+                             int64_t n_rays, float* rays_start, float* rays_dir, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * sample_pts_on_rays.  render_utils.cpp:67-78 / render_utils_kernel.cu:138-236 (K4-K6)
+ * The output length M0 = sum(N_steps) is data dependent, so the op is two-phase:
+ *   1. dvgo_sample_pts_prepare : K1+K2+K3 and the inclusive cumsum of N_steps.
+ *      The caller reads n_steps_cumsum[n_rays-1] (one D2H copy: the reference's own
+ *      `N_steps.sum().item()`, :206) and allocates the M0-sized outputs.
+ *   2. dvgo_sample_pts_fill    : ray_id / step_id / rays_pts / mask_outbbox.
+ * --------------------------------------------------------------------------------- */
+int dvgo_sample_pts_prepare(const float* rays_o, const float* rays_d,
+                            const float* xyz_min, const float* xyz_max,
+                            float near, float far, float stepdist, int64_t n_rays,
+                            float* t_min, float* t_max,            /* [n_rays]         */
+                            int64_t* n_steps,                      /* [n_rays]         */
+                            int64_t* n_steps_cumsum,               /* [n_rays] inclusive */
+                            float* rays_start, float* rays_dir,    /* [n_rays,3]       */
+                            void* stream);
+
+int dvgo_sample_pts_fill(const float* rays_start, const float* rays_dir,
+                         const float* xyz_min, const float* xyz_max,
+                         const int64_t* n_steps_cumsum, int64_t n_rays,
+                         float stepdist, int64_t total_len,        /* M0               */
+                         float* rays_pts,                          /* [M0,3]           */
+                         uint8_t* mask_outbbox,                    /* [M0]             */
+                         int64_t* ray_id, int64_t* step_id,        /* [M0]             */
+                         void* stream);
+
+/* sample_ndc_pts_on_rays.  render_utils.cpp:80-91 / render_utils_kernel.cu:238-287 (K7)
+ * -> rays_pts [n_rays,N_samples,3], mask_outbbox [n_rays,N_samples] */
+int dvgo_sample_ndc_pts_on_rays(const float* rays_o, const float* rays_d,
+                                const float* xyz_min, const float* xyz_max,
+                                int n_samples, int64_t n_rays,
+                                float* rays_pts, uint8_t* mask_outbbox, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * maskcache_lookup.  render_utils.cpp:93-102 / render_utils_kernel.cu:300-351 (K8)
+ * world [sz_i,sz_j,sz_k] bool, xyz [n_pts,3] -> out [n_pts] bool (fully written)
+ * --------------------------------------------------------------------------------- */
+int dvgo_maskcache_lookup(const uint8_t* world, const float* xyz,
+                          const float* xyz2ijk_scale, const float* xyz2ijk_shift,
+                          int sz_i, int sz_j, int sz_k, int64_t n_pts,
+                          uint8_t* out, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * raw2alpha / raw2alpha_backward.  render_utils.cpp:104-114 / _kernel.cu:357-428 (K9,K10)
+ * --------------------------------------------------------------------------------- */
+int dvgo_raw2alpha(const float* density, float shift, float interval, int64_t n_pts,
+                   float* exp_d, float* alpha, void* stream);
+int dvgo_raw2alpha_backward(const float* exp_d, const float* grad_back, float interval,
+                            int64_t n_pts, float* grad, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * alpha2weight / alpha2weight_backward.  render_utils.cpp:116-141 / _kernel.cu:430-561
+ * (K11-K13).  ray_id must be segment-contiguous (as the reference requires).
+ * Outputs of alpha2weight: weight,T [n_pts]; alphainv_last [n_rays]; i_start,i_end [n_rays].
+ * All outputs are fully written (the pre-fills of :478-482 are done here).
+ * The transmittance recurrence is evaluated in the reference's serial order and
+ * precision, so results are bit-identical to the oracle for identical inputs.
+ * --------------------------------------------------------------------------------- */
+int dvgo_alpha2weight(const float* alpha, const int64_t* ray_id, int64_t n_pts, int64_t n_rays,
+                      float* weight, float* T, float* alphainv_last,
+                      int64_t* i_start, int64_t* i_end, void* stream);
+int dvgo_alpha2weight_backward(const float* alpha, const float* weight, const float* T,
+                               const float* alphainv_last, const int64_t* i_start,
+                               const int64_t* i_end, int64_t n_rays, int64_t n_pts,
+                               const float* grad_weights, const float* grad_last,
+                               float* grad /* [n_pts], fully written */, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * Trilinear grid interpolation ("DenseGrid").  Replaces
+ *   lib/dvgo.py:312-328 grid_sampler -> F.grid_sample(grid[1,C,X,Y,Z], ind_norm,
+ *   mode='bilinear', align_corners=True)  and its autograd backward w.r.t. the grid.
+ * The grid is addressed through ELEMENT strides (sC,sX,sY,sZ) so the reference layout
+ * [1,C,X,Y,Z] (sZ=1) and the channels-last layout this library prefers (sC=1) are both
+ * accepted.  xyz [M,3] world coordinates; out / grad_out are [M,C] row-major.
+ * grad_grid must be zero-initialised (or hold a partial sum) -- values are accumulated
+ * with float atomics, so the summation order is not reproducible (neither is the
+ * reference's, run.py:147-149).
+ * --------------------------------------------------------------------------------- */
+int dvgo_grid_sample_fwd(const float* grid, int C, int X, int Y, int Z,
+                         int64_t sC, int64_t sX, int64_t sY, int64_t sZ,
+                         const float* xyz, const float* xyz_min, const float* xyz_max,
+                         int64_t M, float* out, void* stream);
+int dvgo_grid_sample_bwd(const float* grad_out, int C, int X, int Y, int Z,
+                         int64_t sC, int64_t sX, int64_t sY, int64_t sZ,
+                         const float* xyz, const float* xyz_min, const float* xyz_max,
+                         int64_t M, float* grad_grid, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * segment sum.  Replaces torch_scatter.segment_coo(src, index, out, reduce='sum')
+ * (lib/dvgo.py:554-559,571-575).  src [M,C], index [M] int64 sorted/segment-contiguous,
+ * out [N,C] accumulated into (caller zero-fills, as the reference passes out=zeros).
+ * --------------------------------------------------------------------------------- */
+int dvgo_segment_sum(const float* src, const int64_t* index, int64_t M, int C,
+                     int64_t N, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * Fused march (the MI355X-native fast path behind DirectVoxGO.forward, lib/dvgo.py:450-577).
+ * See DESIGN.md "Fused pipeline" for the data flow.  N rays; the per-ray inputs n_steps /
+ * rays_start / rays_dir come from dvgo_sample_pts_prepare (n_steps_cumsum may be NULL there).
+ *
+ * In the dvgo_march_* entry points xyz_min, xyz_max, xyz2ijk_scale and xyz2ijk_shift are
+ * HOST pointers to 3 floats (model constants; they travel as kernel arguments).
+ *
+ * Scratch records.  Each ray owns a slice of the rec2/rec3 scratch arrays that starts at
+ *   n_steps_cumsum[r] - n_steps[r]   when n_steps_cumsum != NULL (exact, M0 records in total), or
+ *   r * rec_stride                   when n_steps_cumsum == NULL (rec_stride >= max n_steps; since
+ *                                    t is clamped to [near,far], ceil((far-near)/stepdist)+1 is a
+ *                                    bound -- saves the scan and the host read of M0).
+ *
+ * dvgo_march_density: one wavefront per ray.  sample -> bbox test -> mask lookup ->
+ *   density trilinear -> raw2alpha -> alpha>thres filter -> transmittance scan with early
+ *   stop (T<1e-3) -> weight>thres filter (both filters only when fast_color_thres > 0,
+ *   lib/dvgo.py:478,488).  Writes per ray r:
+ *     rec2[base+j] (j < n2[r]) : {step, exp_d, alpha, T_before} of the j-th sample that entered
+ *                                compositing (post alpha filter, up to and including the early-stop
+ *                                sample); step has bit 31 set when the sample also passed the
+ *                                weight filter
+ *     rec3[base+k] (k < n3[r]) : {step, weight, alpha, j2} of the k-th sample that survived both
+ *                                filters (the reference's final sample set)
+ *   and n2[r], n3[r], alphainv_last[r].  mask may be NULL (no occupancy skipping).
+ * --------------------------------------------------------------------------------- */
+typedef struct { int32_t step; float exp_d; float alpha; float T; } dvgo_rec2_t;     /* 16 B */
+typedef struct { int32_t step; float weight; float alpha; int32_t j2; } dvgo_rec3_t; /* 16 B */
+
+int dvgo_march_density(const float* rays_start, const float* rays_dir,
+                       const int64_t* n_steps, const int64_t* n_steps_cumsum, int64_t rec_stride,
+                       int64_t n_rays,
+                       const float* xyz_min, const float* xyz_max, float stepdist,
+                       const uint8_t* mask, int mX, int mY, int mZ,
+                       const float* xyz2ijk_scale, const float* xyz2ijk_shift,
+                       const float* density, int X, int Y, int Z,            /* [X,Y,Z] contiguous */
+                       float act_shift, float interval, float fast_color_thres,
+                       dvgo_rec2_t* rec2, dvgo_rec3_t* rec3,
+                       int32_t* n2, int32_t* n3, float* alphainv_last, void* stream);
+
+/* exclusive scan of int32 counts -> int64 offsets [n+1] (offsets[n] = total) */
+int dvgo_exclusive_scan_i32(const int32_t* counts, int64_t n, int64_t* offsets, void* stream);
+
+/* dvgo_march_gather: flat over the M3 = off3[N] surviving samples (ray-major, the reference's
+ *   order).  Writes ray_id, step_id [M3] int64; weights, alpha [M3]; k0 features [M3,C]
+ *   trilinearly interpolated from the feature grid (element strides as dvgo_grid_sample_fwd). */
+int dvgo_march_gather(const dvgo_rec3_t* rec3, const int64_t* n_steps, const int64_t* n_steps_cumsum,
+                      int64_t rec_stride, const int64_t* off3, int64_t n_rays, int64_t M3,
+                      const float* rays_start, const float* rays_dir, float stepdist,
+                      const float* xyz_min, const float* xyz_max,
+                      const float* k0, int C, int X, int Y, int Z,
+                      int64_t sC, int64_t sX, int64_t sY, int64_t sZ,
+                      int64_t* ray_id, int64_t* step_id, float* weights, float* alpha,
+                      float* feat, void* stream);
+
+/* dvgo_march_composite: rgb_marched[r] = sum_k w*rgb + alphainv_last[r]*bg ; optional depth
+ *   = sum_k w*step_id (lib/dvgo.py:554-576).  One wavefront per ray over [off3[r], off3[r+1]). */
+int dvgo_march_composite(const float* weights, const float* rgb /* [M3,3] */,
+                         const int64_t* step_id, const int64_t* off3, int64_t n_rays,
+                         const float* alphainv_last, float bg,
+                         float* rgb_marched /* [N,3] */, float* depth /* [N] or NULL */,
+                         void* stream);
+
+/* Backward of the composite w.r.t. weights and rgb (either output may be NULL):
+ *   grad_weights[i] = sum_c g[r,c]*rgb[i,c] ; grad_rgb[i,c] = g[r,c]*weights[i], r = ray_id[i].
+ *   (d/d alphainv_last = bg * sum_c g[r,c] is an N-sized reduction left to the caller;
+ *   grad_last_add is reserved and ignored.) */
+int dvgo_march_composite_bwd(const float* grad_rgb_marched /* [N,3] */, const float* weights,
+                             const float* rgb, const int64_t* ray_id, int64_t M3, int64_t n_rays,
+                             float bg, float* grad_weights /* [M3] */, float* grad_rgb /* [M3,3] */,
+                             float* grad_last_add, void* stream);
+
+/* dvgo_march_feat_bwd: scatter grad_feat [M3,C] into grad_k0 (float atomics; strides of k0). */
+int dvgo_march_feat_bwd(const float* grad_feat, const int64_t* ray_id, const int64_t* step_id,
+                        int64_t M3, const float* rays_start, const float* rays_dir, float stepdist,
+                        const float* xyz_min, const float* xyz_max,
+                        int C, int X, int Y, int Z, int64_t sC, int64_t sX, int64_t sY, int64_t sZ,
+                        float* grad_k0, void* stream);
+
+/* dvgo_march_density_bwd: one wavefront per ray.  alpha2weight backward (K13) over the rec2
+ *   samples, raw2alpha backward (K10), then the trilinear scatter into grad_density [X,Y,Z].
+ *   grad_weights is indexed in the M3 order of dvgo_march_gather; grad_last may be NULL (= 0). */
+int dvgo_march_density_bwd(const dvgo_rec2_t* rec2, const int32_t* n2, const int64_t* n_steps,
+                           const int64_t* n_steps_cumsum, int64_t rec_stride, const int64_t* off3,
+                           int64_t n_rays,
+                           const float* rays_start, const float* rays_dir, float stepdist,
+                           const float* xyz_min, const float* xyz_max,
+                           const float* alphainv_last, float interval,
+                           const float* grad_weights /* [M3] */, const float* grad_last /* [N] */,
+                           int X, int Y, int Z, float* grad_density, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * "next" rows N1/N2: optimizer and regulariser kernels.
+ *   adam_upd_cuda.{adam_upd,masked_adam_upd,adam_upd_with_perlr}
+ *     (lib/cuda/adam_upd.cpp:36-86, adam_upd_kernel.cu) -- mode 0/1/2, in place.
+ *     step_size is computed by the caller exactly as the reference host code does (:72).
+ *   total_variation_cuda.total_variation_add_grad
+ *     (lib/cuda/total_variation.cpp:16-24, total_variation_kernel.cu) -- in place on grad.
+ * --------------------------------------------------------------------------------- */
+int dvgo_adam_upd(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                  const float* perlr /* mode 2 only */, int64_t n, float step_size,
+                  float beta1, float beta2, float eps, int mode, void* stream);
+
+int dvgo_total_variation_add_grad(const float* param, float* grad, float wx, float wy, float wz,
+                                  int64_t C, int64_t sz_i, int64_t sz_j, int64_t sz_k,
+                                  int64_t sC, int64_t sI, int64_t sJ, int64_t sK,
+                                  int dense_mode, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DVGO_HIP_H */
