@@ -1,0 +1,285 @@
+#!/usr/bin/env python
+"""bench.py -- train rays/sec of the DirectVoxGO ray-marching hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL; see the task contract)
+
+A "step" is one full optimisation step on one batch of rays: fused march forward (sampling,
+mask, density + feature trilinear interpolation, compositing), the rgbnet MLP (torch), the loss of
+run.py:377-386, backward (grid-gradient scatter), gradient all-reduce when N > 1, MaskedAdam over
+all grid elements, lr decay.  Nothing is skipped inside the timed region.
+
+Workload (BASELINE.json): config 2 geometry -- 160^3 fine grid, k0_dim 12, rgbnet 3x128, 8192 rays per
+GPU -- on the 8192 x 256 "roofline case" of SURVEY.md section 8d (every ray yields exactly 256 samples
+and all of them survive both thresholds, M = 2,097,152 per step), synthetic inputs already resident
+in HBM.  A lego-like sparse scene of the same geometry is measured alongside and reported in
+"lego_like".
+
+One JSON line on stdout (rank 0) with the contract's fields plus
+  roofline     : the dominant hot-path kernel -- algorithmic bytes per launch / average launch
+                 duration measured with HIP events on the launching stream inside the timed region
+  kernels      : the same for every hot-path kernel
+  cpu_baseline : the CPU oracle ("port") timed on this host on a bounded sample of the same workload
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+
+HOT_KERNELS = ['dvgo_sample_pts_prepare', 'dvgo_march_density', 'dvgo_exclusive_scan_i32', 'dvgo_march_gather',
+               'dvgo_march_composite', 'dvgo_march_composite_bwd', 'dvgo_march_feat_bwd', 'dvgo_march_density_bwd',
+               'dvgo_adam_upd']
+
+
+def algorithmic_bytes(name, N, M_d, M2, M_k, C, n_grid):
+    """SURVEY.md section 8d, per launch.  M_d: samples whose density is interpolated, M_k: samples whose
+    features are interpolated.  Scratch/ids that only exist because of how the work is split are not counted."""
+    return {
+        'dvgo_sample_pts_prepare': N * (24 + 4 + 4 + 8 + 24),
+        'dvgo_march_density': M_d * (8 * 4 + 1 + 4 + 4) + N * 40,          # corner gathers, mask byte, alpha, w
+        'dvgo_exclusive_scan_i32': N * 12,
+        'dvgo_march_gather': M_k * (8 * C * 4 + C * 4),                     # feature gathers + [M_k,C] write
+        'dvgo_march_composite': M_k * 16 + N * 16,
+        'dvgo_march_composite_bwd': M_k * 32,
+        'dvgo_march_feat_bwd': M_k * (8 * C * 4 + C * 4),                   # each atomic counted once as 4 B
+        'dvgo_march_density_bwd': M2 * (8 * 4 + 16),
+        'dvgo_adam_upd': None,                                              # per call: 28 B / element (dense)
+    }[name]
+
+
+def build(workload, world, n_rays, device, seed):
+    from directvoxgo_amd.dvgo import DirectVoxGO
+    from directvoxgo_amd.scenes import roofline_scene, synthetic_scene
+    if workload == 'roofline':
+        sc = roofline_scene(world=world, n_rays=n_rays, seed=seed, device=device)
+    else:
+        sc = synthetic_scene(world=world, n_rays=n_rays, seed=seed, device=device)
+    torch.manual_seed(777)       # identical MLP init on every rank
+    m = DirectVoxGO(sc['xyz_min'], sc['xyz_max'], num_voxels=world ** 3, num_voxels_base=world ** 3, alpha_init=1e-2,
+                    fast_color_thres=1e-4, rgbnet_dim=12, rgbnet_depth=3, rgbnet_width=128, viewbase_pe=4, fused=True)
+    m = m.to(device)
+    return sc, m
+
+
+def load_state(m, sc):
+    with torch.no_grad():
+        m.density.copy_(sc['density']); m.k0.copy_(sc['k0']); m.mask_cache.mask.copy_(sc['mask'])
+
+
+def ray_pool(workload, half, n_rays, device, base_seed, n_batches):
+    from directvoxgo_amd import scenes
+    pool = []
+    for b in range(n_batches):
+        gen = torch.Generator().manual_seed(base_seed + 17 * b)
+        if workload == 'roofline':
+            ro, rd = scenes.roofline_rays(n_rays, gen, half)
+            vd = rd.clone()
+        else:
+            ro, rd, vd = scenes.lego_like_rays(n_rays, gen)
+        tgt = torch.rand((n_rays, 3), generator=gen)
+        pool.append(tuple(t.to(device).contiguous() for t in (ro, rd, vd, tgt)))
+    return pool
+
+
+def count_samples(m, batch, rk):
+    """M0 / M_d (= M1) / M2 / M_k (= M3) of one batch, outside any timed region."""
+    from directvoxgo_amd import render_utils as ru
+    ro, rd, vd, _ = batch
+    with torch.no_grad():
+        stepdist = rk['stepsize'] * m.voxel_size
+        pts, mo, rid, sid, n_steps, _, _ = ru.sample_pts_on_rays(ro, rd, m.xyz_min, m.xyz_max, rk['near'], rk['far'], stepdist)
+        M0 = int(pts.shape[0])
+        pts = pts[~mo]
+        M1 = int(m.mask_cache(pts).sum())
+        res = m(ro, rd, vd, **rk)
+        M3 = int(res['weights'].numel())
+    return M0, M1, M3
+
+
+def timed_region(step_fn, pool, steps, warmup, world, profile=True):
+    from directvoxgo_amd import _lib as L
+    for i in range(warmup):
+        step_fn(*pool[i % len(pool)], global_step=5000 + i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    if profile:
+        L.profile_start(HOT_KERNELS)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step_fn(*pool[(warmup + i) % len(pool)], global_step=5000 + warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    prof = L.profile_stop() if profile else {}
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, prof
+
+
+def cpu_baseline(sc_cpu, m, rk, n_rays_total, sample_rays):
+    """The CPU oracle ("port": oracle/dvgo_oracle.c, scalar, 1 thread; MLP by torch CPU on 1 thread) on a
+    bounded sample: the first `sample_rays` rays of the same workload through the march forward +
+    backward, extrapolated to a full batch, plus one full Adam sweep."""
+    from oracle import oracle as O
+    torch.set_num_threads(1)
+    mn, mx = sc_cpu['xyz_min'].numpy(), sc_cpu['xyz_max'].numpy()
+    ro, rd = sc_cpu['rays_o'][:sample_rays].numpy(), sc_cpu['rays_d'][:sample_rays].numpy()
+    vd = sc_cpu['viewdirs'][:sample_rays]
+    density = sc_cpu['density'][0].numpy()
+    k0 = sc_cpu['k0'][0].numpy()
+    mask = sc_cpu['mask'].numpy()
+    stepdist = np.float32(rk['stepsize']) * m.voxel_size.numpy()
+    interval = np.float32(rk['stepsize']) * m.voxel_size_ratio.numpy()
+    import copy
+    rgbnet = copy.deepcopy(m.rgbnet).cpu()
+    t0 = time.perf_counter()
+    pts, mo, rid, sid, *_ = O.sample_pts_on_rays(ro, rd, mn, mx, rk['near'], rk['far'], stepdist)
+    pts, rid, sid = pts[~mo], rid[~mo], sid[~mo]
+    scale = (np.array(mask.shape, np.float32) - 1) / (mx - mn)
+    k = O.maskcache_lookup(mask, pts, scale, -mn * scale)
+    pts, rid, sid = pts[k], rid[k], sid[k]
+    dens = O.grid_sample_fwd(density, pts, mn, mx)[:, 0]
+    e, alpha = O.raw2alpha(dens, m.act_shift, interval)
+    k = alpha > m.fast_color_thres
+    pts2, rid2, e2, alpha2 = pts[k], rid[k], e[k], alpha[k]
+    w, T, last, i_s, i_e = O.alpha2weight(alpha2, rid2, sample_rays)
+    k3 = w > m.fast_color_thres
+    pts3, rid3, w3 = pts2[k3], rid2[k3], w[k3]
+    feat = torch.from_numpy(O.grid_sample_fwd(k0, pts3, mn, mx)).requires_grad_()
+    emb = (vd.unsqueeze(-1) * m.viewfreq.cpu()).flatten(-2)
+    emb = torch.cat([vd, emb.sin(), emb.cos()], -1)[torch.from_numpy(rid3)]
+    rgb = torch.sigmoid(rgbnet(torch.cat([feat[:, 3:], emb], -1)) + feat[:, :3])
+    wt = torch.from_numpy(w3).requires_grad_()
+    marched = torch.from_numpy(O.segment_sum((wt.detach()[:, None] * rgb.detach()).numpy(), rid3, sample_rays))
+    g_marched = (2 * (marched + torch.from_numpy(last)[:, None] - sc_cpu['target'][:sample_rays]) / (3 * n_rays_total))
+    g_per_sample = g_marched[torch.from_numpy(rid3)]
+    (rgb * (g_per_sample * wt.detach()[:, None])).sum().backward()       # MLP backward -> grad feat
+    g_w = np.zeros_like(w); g_w[k3] = (g_per_sample * rgb.detach()).sum(-1).numpy()
+    g_alpha = O.alpha2weight_backward(alpha2, w, T, last, i_s, i_e, sample_rays, g_w, g_marched.sum(-1).numpy().astype(np.float32))
+    g_dens = O.raw2alpha_backward(e2, g_alpha, interval)
+    O.grid_sample_bwd(g_dens[:, None], (1, *density.shape[1:]), pts2, mn, mx)
+    O.grid_sample_bwd(feat.grad.numpy(), k0.shape, pts3, mn, mx)
+    t_march = time.perf_counter() - t0
+    # one full MaskedAdam sweep over the grids (53 M elements at 160^3 x 13)
+    n_el = density.size + k0.size
+    p = np.zeros(n_el, np.float32); g = np.ones(n_el, np.float32); a = np.zeros(n_el, np.float32); b = np.zeros(n_el, np.float32)
+    t0 = time.perf_counter()
+    O.adam_upd(p, g, a, b, 1, 0.9, 0.99, 0.1, 1e-8, mode=1)
+    t_adam = time.perf_counter() - t0
+    t_step = t_march * (n_rays_total / sample_rays) + t_adam
+    return {'value': n_rays_total / t_step, 'unit': 'rays/s', 'cores': 1, 'kind': 'port',
+            'sample': f'{sample_rays} of {n_rays_total} rays x {int(len(pts) / max(sample_rays, 1))} samples/ray through '
+                      f'oracle march fwd+bwd + torch-CPU rgbnet fwd+bwd on 1 thread ({t_march:.2f} s, extrapolated x'
+                      f'{n_rays_total // sample_rays}) + one full oracle MaskedAdam sweep over {n_el} grid elements '
+                      f'({t_adam:.2f} s)',
+            'host_cpus': os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--world', type=int, default=160, help='grid resolution per axis')
+    ap.add_argument('--rays', type=int, default=8192, help='rays per GPU per step')
+    ap.add_argument('--workload', default='roofline', choices=['roofline', 'lego'])
+    ap.add_argument('--no-secondary', action='store_true', help='skip the lego-like secondary measurement')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-sample-rays', type=int, default=512)
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    else:
+        torch.cuda.set_device(0)
+    assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    device = torch.device('cuda', local_rank if world > 1 else 0)
+
+    from directvoxgo_amd.train import FINE_TRAIN, TrainStep
+
+    def run(workload, steps, warmup, profile):
+        sc, m = build(workload, args.world, args.rays, device, seed=777)
+        load_state(m, sc)
+        rk = dict(near=sc['near'], far=sc['far'], bg=1, stepsize=sc['stepsize'])
+        pool = ray_pool(workload, float(sc['xyz_max'][0]), args.rays, device, base_seed=777 + 1000 * rank, n_batches=4)
+        M0, M_d, M_k = count_samples(m, pool[0], rk)
+        step = TrainStep(m, dict(FINE_TRAIN), rk)
+        dt, prof = timed_region(step, pool, steps, warmup, world, profile)
+        return sc, m, rk, dt, prof, (M0, M_d, M_k)
+
+    sc, m, rk, dt, prof, (M0, M_d, M_k) = run(args.workload, args.steps, args.warmup, True)
+    n_total = args.rays * world
+    value = n_total * args.steps / dt
+
+    C = m.k0_dim
+    n_grid = m.density.numel() + m.k0.numel()
+    kernels = {}
+    for name, (cnt, ms) in prof.items():
+        if cnt == 0:
+            continue
+        per_ms = ms / cnt
+        ab = algorithmic_bytes(name, args.rays, M_d, M_k if args.workload == 'roofline' else M_k, M_k, C, n_grid)
+        if name == 'dvgo_adam_upd':
+            ab = 28 * n_grid / max(cnt / args.steps, 1)          # average per call over the param tensors
+        kernels[name] = {'launches': cnt, 'avg_ms': per_ms, 'alg_bytes': ab,
+                         'GBps': ab / per_ms / 1e6, 'frac': ab / per_ms / 1e6 / HBM_PEAK_GBS}
+    march = {k: v for k, v in kernels.items() if k in ('dvgo_march_gather', 'dvgo_march_feat_bwd', 'dvgo_march_density',
+                                                        'dvgo_march_density_bwd')}
+    dom = max(march, key=lambda k: march[k]['avg_ms']) if march else None
+    roofline = None
+    if dom:
+        roofline = {'kernel': dom, 'bound': 'hbm', 'achieved': kernels[dom]['GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': kernels[dom]['frac'], 'traffic': None, 'alg_bytes_per_launch': kernels[dom]['alg_bytes'],
+                    'avg_launch_ms': kernels[dom]['avg_ms']}
+
+    out = {
+        'metric': 'train rays/sec (8192-ray batch, 160^3 grid)', 'value': value, 'unit': 'rays/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': f'cfg2 {args.workload}: {args.world}^3 fine grid, k0_dim 12 + rgbnet 3x128, '
+                               f'{args.rays} rays/GPU x {M0 // args.rays} samples/ray '
+                               f'(M_d={M_d}, M_k={M_k} per GPU per step), full train step',
+                   'rays_per_gpu': args.rays, 'grid': args.world, 'parallelism': f'ray-dp{world}'},
+        'roofline': roofline, 'kernels': kernels,
+    }
+
+    if rank == 0 and world == 1 and not args.no_secondary and args.workload == 'roofline':
+        sc2, m2, rk2, dt2, prof2, (M0b, M_db, M_kb) = run('lego', max(args.steps, 20), args.warmup, False)
+        out['lego_like'] = {'value': args.rays * max(args.steps, 20) / dt2, 'unit': 'rays/s',
+                            'ms_per_step': dt2 / max(args.steps, 20) * 1e3, 'occupancy': sc2['occupancy'],
+                            'samples_per_ray': {'M0': M0b / args.rays, 'M_d': M_db / args.rays, 'M_k': M_kb / args.rays}}
+        del sc2, m2
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sc_cpu = {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in sc.items()}
+        out['cpu_baseline'] = cpu_baseline(sc_cpu, m, rk, args.rays, args.cpu_sample_rays)
+    elif rank == 0:
+        out['cpu_baseline'] = None
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -67,8 +67,35 @@ def stream_of(t):
 _ERR = {-1: 'invalid argument', -2: 'size exceeds 32-bit launch range'}
 
 
+# Optional per-entry-point timing with HIP events on the launching (= torch's current) stream.
+# bench.py uses it to measure the average launch duration of the hot kernels inside its timed
+# region; it is off (None) everywhere else.
+_profile = None
+
+
+def profile_start(names):
+    global _profile
+    _profile = {n: [] for n in names}
+
+
+def profile_stop():
+    """-> {name: (launches, total_ms)}; synchronises."""
+    global _profile
+    prof, _profile = _profile, None
+    torch.cuda.synchronize()
+    return {n: (len(ev), sum(a.elapsed_time(b) for a, b in ev)) for n, ev in (prof or {}).items()}
+
+
 def call(name, *args):
-    rc = getattr(lib(), name)(*args)
+    fn = getattr(lib(), name)
+    if _profile is not None and name in _profile:
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        rc = fn(*args)
+        b.record()
+        _profile[name].append((a, b))
+    else:
+        rc = fn(*args)
     if rc != 0:
         raise RuntimeError(f'{name} failed: {_ERR.get(rc, "hipError %d" % rc)}')
 

@@ -94,6 +94,22 @@ def synthetic_scene(world=160, n_rays=8192, seed=777, device='cpu', k0_dim=12, a
     return sc
 
 
+def roofline_rays(n_rays, gen, half):
+    """Unit-direction chords from one face of the cube [-half, half]^3 (1e-4 inside) to the opposite
+    face, every other coordinate strictly inside: chord length >= 2*half - 2e-4."""
+    axis = torch.randint(3, (n_rays,), generator=gen)
+    side = torch.randint(2, (n_rays,), generator=gen).float() * 2 - 1
+    inset = half * (1 - 2e-3)
+    o = (torch.rand((n_rays, 3), generator=gen) * 2 - 1) * inset
+    t = (torch.rand((n_rays, 3), generator=gen) * 2 - 1) * inset
+    idx = torch.arange(n_rays)
+    o[idx, axis] = -side * (half - 1e-4)
+    t[idx, axis] = side * (half - 1e-4)
+    d = t - o
+    d = d / d.norm(dim=-1, keepdim=True)
+    return o.contiguous(), d.contiguous()
+
+
 def roofline_scene(world=160, n_rays=8192, n_samples=256, seed=777, device='cpu', k0_dim=12, bbox=1.5,
                    bound_scale=1.05, stepsize=0.5):
     """The 8192 x 256 roofline case of SURVEY.md section 8d.  Every ray is a unit-direction chord
@@ -107,16 +123,7 @@ def roofline_scene(world=160, n_rays=8192, n_samples=256, seed=777, device='cpu'
     ws = (world, world, world)
     voxel_size = ((mx - mn).prod() / world ** 3).pow(1 / 3)
     stepdist = float(stepsize * voxel_size)
-    axis = torch.randint(3, (n_rays,), generator=gen)
-    side = torch.randint(2, (n_rays,), generator=gen).float() * 2 - 1
-    inset = half * (1 - 2e-3)          # keep the whole chord strictly inside the box
-    o = (torch.rand((n_rays, 3), generator=gen) * 2 - 1) * inset
-    t = (torch.rand((n_rays, 3), generator=gen) * 2 - 1) * inset
-    idx = torch.arange(n_rays)
-    o[idx, axis] = -side * (half - 1e-4)
-    t[idx, axis] = side * (half - 1e-4)
-    d = t - o
-    d = d / d.norm(dim=-1, keepdim=True)
+    o, d = roofline_rays(n_rays, gen, half)
     far = (n_samples - 0.5) * stepdist
     assert far < 2 * half - 1e-2, 'chord shorter than the sampled span'
     density = torch.randn((1, 1, *ws), generator=gen) * 0.1

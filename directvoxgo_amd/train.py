@@ -1,0 +1,119 @@
+"""Training step of the hot path (harness row H3 of SURVEY.md section 8a) and its ray-parallel
+data-parallel form (section 8e).
+
+Counterpart of /root/reference/run.py:348-407: loss terms and weights (:377-386), gradient step
+with ``zero_grad(set_to_none=True)`` before backward (:376), optional TV add-grad (:389-395),
+MaskedAdam step (:397) and the per-step lr decay (:401-406); optimizer construction follows
+lib/utils.py:20-48.
+
+Data parallelism (the reference has none): one process per GPU, rays sharded,
+grids / MLP / optimizer state replicated.  Every loss term is normalised by the GLOBAL ray
+count so that the sum of the per-rank gradients equals the single-process gradient; the grid
+gradients are summed with one all-reduce each (RCCL over xGMI; `backend='nccl'` on ROCm) and
+the small MLP gradients travel in one flat bucket.  TV and the masked Adam run after the
+reduction because both branch on ``grad != 0`` (total_variation_kernel.cu:21,
+adam_upd_kernel.cu:35) and must see the reduced gradient.
+"""
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from .masked_adam import MaskedAdam
+
+COARSE_TRAIN = dict(
+    N_iters=5000, N_rand=8192, lrate_density=1e-1, lrate_k0=1e-1, lrate_rgbnet=1e-3, lrate_decay=20,
+    pervoxel_lr=True, weight_main=1.0, weight_entropy_last=0.01, weight_rgbper=0.1,
+    tv_every=1, tv_after=0, tv_before=0, tv_dense_before=0, weight_tv_density=0.0, weight_tv_k0=0.0,
+    pg_scale=[], skip_zero_grad_fields=[])            # configs/default.py:36-57
+FINE_TRAIN = dict(COARSE_TRAIN, N_iters=20000, pervoxel_lr=False, weight_entropy_last=0.001, weight_rgbper=0.01,
+                  pg_scale=[1000, 2000, 3000, 4000], skip_zero_grad_fields=['density', 'k0'])   # :59-68
+
+
+def create_optimizer_or_freeze_model(model, cfg_train, global_step):
+    """lib/utils.py:20-48: one param group per `lrate_<name>` whose attribute exists on the model."""
+    decay_steps = cfg_train['lrate_decay'] * 1000
+    decay_factor = 0.1 ** (global_step / decay_steps)
+    groups = []
+    for key in cfg_train:
+        if not key.startswith('lrate_'):
+            continue
+        name = key[len('lrate_'):]
+        if not hasattr(model, name):
+            continue
+        param = getattr(model, name)
+        if param is None:
+            continue
+        lr = cfg_train[key] * decay_factor
+        if lr > 0:
+            if isinstance(param, nn.Module):
+                param = param.parameters()
+            groups.append({'params': param, 'lr': lr, 'skip_zero_grad': name in cfg_train['skip_zero_grad_fields']})
+        elif not isinstance(param, dict):
+            param.requires_grad = False
+    return MaskedAdam(groups)
+
+
+def render_loss(render_result, target, n_rays_global, cfg_train):
+    """run.py:377-386 with every mean written as sum / global count (identical for one rank)."""
+    d = render_result['rgb_marched'] - target
+    loss = cfg_train['weight_main'] * d.pow(2).sum() / (3 * n_rays_global)
+    if cfg_train['weight_entropy_last'] > 0:
+        pout = render_result['alphainv_last'].clamp(1e-6, 1 - 1e-6)
+        ent = -(pout * torch.log(pout) + (1 - pout) * torch.log(1 - pout)).sum() / n_rays_global
+        loss = loss + cfg_train['weight_entropy_last'] * ent
+    if cfg_train['weight_rgbper'] > 0:
+        rgbper = (render_result['raw_rgb'] - target[render_result['ray_id']]).pow(2).sum(-1)
+        loss = loss + cfg_train['weight_rgbper'] * ((rgbper * render_result['weights'].detach()).sum() / n_rays_global)
+    return loss
+
+
+class TrainStep:
+    """One optimisation step on one batch of rays; ``world_size > 1`` shards the batch by rank."""
+
+    def __init__(self, model, cfg_train, render_kwargs, optimizer=None, process_group=None):
+        self.model = model
+        self.cfg = cfg_train
+        self.render_kwargs = render_kwargs
+        self.optimizer = optimizer or create_optimizer_or_freeze_model(model, cfg_train, global_step=0)
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.decay_factor = 0.1 ** (1 / (cfg_train['lrate_decay'] * 1000))
+        self._small = [p for n, p in model.named_parameters() if n not in ('density', 'k0') and p.requires_grad]
+
+    def reduce_gradients(self):
+        """Sum the per-rank gradients (section 8e).  Two large collectives (the grids are reduced in
+        place, no staging copy) and one flat bucket for the MLP."""
+        if self.world == 1:
+            return
+        for p in (self.model.density, self.model.k0):
+            if p.grad is not None:
+                dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.pg)
+        small = [p for p in self._small if p.grad is not None]
+        if small:
+            flat = torch.cat([p.grad.reshape(-1) for p in small])
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg)
+            off = 0
+            for p in small:
+                n = p.grad.numel()
+                p.grad.copy_(flat[off:off + n].view_as(p.grad))
+                off += n
+
+    def __call__(self, rays_o, rays_d, viewdirs, target, global_step):
+        """rays are this rank's shard; returns the (local share of the) loss as a 0-dim tensor."""
+        cfg, model = self.cfg, self.model
+        n_global = rays_o.shape[0] * self.world
+        res = model(rays_o, rays_d, viewdirs, global_step=global_step, **self.render_kwargs)
+        self.optimizer.zero_grad(set_to_none=True)
+        loss = render_loss(res, target, n_global, cfg)
+        loss.backward()
+        self.reduce_gradients()
+        if cfg['tv_after'] < global_step < cfg['tv_before'] and global_step % cfg['tv_every'] == 0:   # run.py:389-395
+            dense = global_step < cfg['tv_dense_before']
+            if cfg['weight_tv_density'] > 0:
+                model.density_total_variation_add_grad(cfg['weight_tv_density'] / n_global, dense)
+            if cfg['weight_tv_k0'] > 0:
+                model.k0_total_variation_add_grad(cfg['weight_tv_k0'] / n_global, dense)
+        self.optimizer.step()
+        for group in self.optimizer.param_groups:                                                  # run.py:401-406
+            group['lr'] = group['lr'] * self.decay_factor
+        return loss.detach()
