@@ -1,0 +1,125 @@
+"""CPU, world_size 2, gloo: the ray-parallel data-parallel step.
+
+The HIP ops need a GPU, so the N > 1 *host logic* is exercised with a small pure-torch stand-in model
+that returns the same result dict as DirectVoxGO.forward: rays sharded by rank, every loss term
+normalised by the global ray count, grid gradients summed with all-reduce, MLP gradients in one flat
+bucket, optimizer step after the reduction.  Two ranks on half the batch each must end at exactly the
+parameters one process reaches on the whole batch.
+"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+import torch.nn.functional as F
+
+from directvoxgo_amd.train import FINE_TRAIN, TrainStep, render_loss
+
+
+class ToyModel(nn.Module):
+    """Same parameter names / result dict as DirectVoxGO, pure torch, S fixed samples per ray."""
+
+    def __init__(self, S=6):
+        super().__init__()
+        g = torch.Generator().manual_seed(5)
+        self.density = nn.Parameter(torch.randn(1, 1, 5, 5, 5, generator=g))
+        self.k0 = nn.Parameter(torch.randn(1, 6, 5, 5, 5, generator=g) * 0.3)
+        self.rgbnet = nn.Sequential(nn.Linear(6, 8), nn.ReLU(), nn.Linear(8, 3))
+        for p in self.rgbnet.parameters():
+            p.data = torch.randn(p.shape, generator=g) * 0.3
+        self.S = S
+
+    def forward(self, rays_o, rays_d, viewdirs, global_step=None, bg=1, **kw):
+        N = rays_o.shape[0]
+        t = torch.linspace(0.1, 0.9, self.S)
+        pts = rays_o[:, None] + rays_d[:, None] * t[None, :, None]                  # [N,S,3] in [-1,1]
+        grid = pts.reshape(1, 1, 1, -1, 3).flip(-1)
+        dens = F.grid_sample(self.density, grid, align_corners=True).reshape(-1)
+        feat = F.grid_sample(self.k0, grid, align_corners=True).reshape(6, -1).T
+        alpha = (1 - torch.exp(-F.softplus(dens))).reshape(N, self.S)
+        T = torch.cumprod(torch.cat([torch.ones(N, 1), 1 - alpha + 1e-10], 1), 1)
+        weights = (T[:, :-1] * alpha).reshape(-1)
+        rgb = torch.sigmoid(self.rgbnet(feat))
+        ray_id = torch.arange(N).repeat_interleave(self.S)
+        marched = torch.zeros(N, 3).index_add(0, ray_id, weights[:, None] * rgb) + T[:, -1:] * bg
+        return {'alphainv_last': T[:, -1], 'weights': weights, 'rgb_marched': marched, 'raw_alpha': alpha.reshape(-1),
+                'raw_rgb': rgb, 'ray_id': ray_id}
+
+
+def make_batch(n):
+    g = torch.Generator().manual_seed(11)
+    ro = torch.rand(n, 3, generator=g) * 0.4 - 0.2
+    rd = torch.rand(n, 3, generator=g) * 1.2 - 0.6
+    return ro, rd, rd / rd.norm(dim=-1, keepdim=True), torch.rand(n, 3, generator=g)
+
+
+def run_steps(model, batch, rank, world, n_steps=3):
+    cfg = dict(FINE_TRAIN, weight_entropy_last=0.01, weight_rgbper=0.05)
+    opt = torch.optim.SGD(model.parameters(), lr=0.5)
+    step = TrainStep(model, cfg, dict(bg=1), optimizer=opt)
+    n = batch[0].shape[0] // world
+    shard = tuple(t[rank * n:(rank + 1) * n] for t in batch)
+    losses = []
+    for s in range(n_steps):
+        losses.append(step(*shard, global_step=s))
+    return torch.stack(losses)
+
+
+def _worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    model = ToyModel()
+    losses = run_steps(model, make_batch(32), rank, world)
+    dist.all_reduce(losses)           # per-rank shares of the global loss add up to it
+    if rank == 0:
+        # numpy: pickled by value (torch tensors would travel as shared-memory handles of a process about to exit)
+        q.put(({k: v.detach().numpy().copy() for k, v in model.state_dict().items()}, losses.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.timeout(120)
+def test_two_ranks_equal_one_process():
+    ref_model = ToyModel()
+    ref_losses = run_steps(ref_model, make_batch(32), 0, 1)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    sd, losses = q.get(timeout=100)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert torch.allclose(torch.from_numpy(losses), ref_losses, rtol=1e-5, atol=1e-7)
+    for k, v in ref_model.state_dict().items():
+        assert torch.allclose(torch.from_numpy(sd[k]), v, rtol=1e-5, atol=1e-6), k
+
+
+def test_render_loss_equals_reference_formula_on_one_rank():
+    """run.py:377-386 written with means == the sum / global-count form used for DP."""
+    m = ToyModel()
+    ro, rd, vd, tgt = make_batch(16)
+    res = m(ro, rd, vd)
+    cfg = dict(FINE_TRAIN)
+    a = render_loss(res, tgt, 16, cfg)
+    b = cfg['weight_main'] * F.mse_loss(res['rgb_marched'], tgt)
+    pout = res['alphainv_last'].clamp(1e-6, 1 - 1e-6)
+    b = b + cfg['weight_entropy_last'] * (-(pout * torch.log(pout) + (1 - pout) * torch.log(1 - pout)).mean())
+    rgbper = (res['raw_rgb'] - tgt[res['ray_id']]).pow(2).sum(-1)
+    b = b + cfg['weight_rgbper'] * ((rgbper * res['weights'].detach()).sum() / 16)
+    assert torch.allclose(a, b, rtol=1e-6)

@@ -106,3 +106,29 @@ def test_rec_stride_bound():
     assert _rec_stride(cfg, 8192) == 429            # ceil(4 / 0.009375) + 2
     cfg.far = 1e9
     assert _rec_stride(cfg, 8192) == 0              # falls back to the exact (cumsum) layout
+
+
+@pytest.mark.skipif(not __import__('os').path.isdir('/root/reference/lib'), reason='reference tree only exists in the build container')
+def test_compat_shim_binds_reference_modules_by_name(tmp_path):
+    """directvoxgo_amd.compat.install(): an unmodified copy of the reference's lib/dvgo.py and
+    lib/masked_adam.py picks up the HIP op modules where it calls cpp_extension.load(name=...)."""
+    import shutil
+    import subprocess
+    import sys
+    shutil.copytree('/root/reference/lib', tmp_path / 'lib', ignore=shutil.ignore_patterns('cuda', '__pycache__'))
+    (tmp_path / 'lib' / '__init__.py').touch()
+    code = (
+        "import sys; sys.dont_write_bytecode = True\n"
+        f"sys.path.insert(0, {str(tmp_path)!r}); sys.path.insert(0, {str(__import__('conftest').REPO)!r})\n"
+        "import directvoxgo_amd.compat as compat; compat.install()\n"
+        "import lib.dvgo as d, lib.masked_adam as ma\n"
+        "import directvoxgo_amd.render_utils as ru, directvoxgo_amd.ops as ops\n"
+        "assert d.render_utils_cuda is ru\n"
+        "assert d.segment_coo is ops.segment_coo\n"
+        "assert d.total_variation_cuda.total_variation_add_grad is ops.total_variation_add_grad\n"
+        "assert callable(ma.adam_upd_cuda.masked_adam_upd)\n"
+        "m = d.DirectVoxGO([-1,-1,-1],[1,1,1], num_voxels=512, num_voxels_base=512, alpha_init=1e-2, fast_color_thres=1e-4)\n"
+        "print('ok', tuple(m.density.shape))\n")
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert 'ok (1, 1, 8, 8, 8)' in out.stdout
