@@ -15,6 +15,8 @@
 //
 // and the backward mirrors it (composite_bwd, feat_bwd, density_bwd).  Filter order is the
 // reference's: mask -> alpha > thres (before transmittance) -> T < 1e-3 stop -> weight > thres.
+#include <stdlib.h>
+
 #include "common.h"
 
 __device__ __forceinline__ unsigned long long lanemask_lt(int lane) {
@@ -52,6 +54,9 @@ __device__ __forceinline__ int64_t rec_base(const int64_t* __restrict__ cum, con
                                             int64_t rec_stride, int64_t ray) {
   return cum ? (cum[ray] - n_steps[ray]) : ray * rec_stride;
 }
+
+// run-time selectable kernel variants (A/B measurements in one process; defaults = fastest measured)
+static int g_tuning[DVGO_TUNE_COUNT] = {1, 1, 0, 0, 0, 0, 0, 0};
 
 struct MarchParams {
   float mnx, mny, mnz, mxx, mxy, mxz;
@@ -296,10 +301,159 @@ march_feat_bwd_kernel(const float* __restrict__ grad_feat, const int64_t* __rest
 }
 
 // ----------------------------------------------------------------------------------
+// march_feat_bwd, de-duplicating form (channels-last grids).
+//
+// Float atomics leave the chip as 64-B memory-side requests at a fixed chip-wide rate
+// (MI355X_MICROARCH "Global float atomics"; measured here: 29.5 M requests in 1.50 ms = 19.7 G/s for
+// the one-atomic-per-(sample,corner,channel) form), so the scatter is bound by how many corner rows
+// are emitted, not by HBM.  Consecutive samples of a ray are half a voxel apart and share most of
+// their corners, so every wavefront first groups the 256 corner references of SPP = 32 consecutive
+// samples by voxel and emits each distinct corner once, as one contiguous 4*C-byte row.
+//
+// Grouping is a counting sort in the wave's private LDS, built so that the accumulation itself needs
+// no LDS float atomics (those serialise on equal addresses, which is exactly the case being merged;
+// a first version that accumulated with ds_add_f32 was LDS-bound at 1.23 ms):
+//   A  lanes = (sample, half of its 8 corners); insert the corner's voxel index into an open-addressing
+//      table (atomicCAS), take a ticket in the slot's reference counter;
+//   B  list the occupied slots and exclusive-scan their counters (wave prefix sum);
+//   C  every reference writes {weight, sample} at offset[slot] + ticket;
+//   D  owner computes: C adjacent lanes own one corner row, walk its references, read the sample's
+//      gradient row from LDS, accumulate in a register, emit ONE global atomic per (corner, channel).
+// A corner that cannot be placed within the probe bound falls back to direct global atomics.
+// ----------------------------------------------------------------------------------
+template <int C>
+__global__ void __launch_bounds__(DVGO_BLOCK)
+march_feat_bwd_dedup_kernel(const float* __restrict__ grad_feat, const int64_t* __restrict__ ray_id,
+                            const int64_t* __restrict__ step_id, int64_t M3,
+                            const float* __restrict__ rays_start, const float* __restrict__ rays_dir,
+                            MarchParams P, float* __restrict__ grad_k0) {
+  constexpr int H = 256;        // table slots per wave (>= corner references per pass)
+  constexpr int SPP = 32;       // samples per pass
+  constexpr int RPI = 64 / C;   // corner rows per atomic wave-instruction
+  struct WaveLds {
+    int keys[H];
+    int cnts[H];
+    int offs[H];
+    int list[H];
+    float ref_w[H];
+    int ref_s[H];
+    float g[SPP][C];
+  };
+  __shared__ __attribute__((aligned(16))) WaveLds s_lds[4];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  WaveLds& L = s_lds[wave];
+  for (int s = lane; s < H; s += 64) { L.keys[s] = -1; L.cnts[s] = 0; }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  const unsigned long long lt = lanemask_lt(lane);
+  const int64_t n_pass = (M3 + SPP - 1) / SPP;
+  const int64_t gwave = (int64_t)blockIdx.x * 4 + wave, nwaves = (int64_t)gridDim.x * 4;
+  const int YZ = P.Y * P.Z;
+  const int rsub = lane / C, ch = lane - rsub * C;
+  for (int64_t pass = gwave; pass < n_pass; pass += nwaves) {
+    const int sl = lane >> 1, half = lane & 1;
+    const int64_t i = pass * SPP + sl;
+    int slot[4], tick[4];
+    float wq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { slot[q] = -1; tick[q] = 0; wq[q] = 0.0f; }
+    // ---- A: table insert + tickets
+    if (i < M3) {
+      float px, py, pz;
+      dvgo_sample_pos(rays_start, rays_dir, ray_id[i], P.stepdist, (int)step_id[i], px, py, pz);
+      const TriSetup t = dvgo_tri_setup(px, py, pz, P.mnx, P.mny, P.mnz, P.mxx, P.mxy, P.mxz, P.X, P.Y, P.Z);
+      const float4* gp = reinterpret_cast<const float4*>(grad_feat + i * C);
+      float4 gv[C / 4];
+#pragma unroll
+      for (int c = 0; c < C / 4; ++c) gv[c] = gp[c];
+      if (half == 0) {
+        float4* dst = reinterpret_cast<float4*>(&L.g[sl][0]);
+#pragma unroll
+        for (int c = 0; c < C / 4; ++c) dst[c] = gv[c];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = half * 4 + q;
+        if (!dvgo_tri_inb(t, n, P.X, P.Y, P.Z)) continue;
+        const float w = dvgo_tri_weight(t, n);
+        if (w == 0.0f) continue;
+        const int key = (t.i0 + ((n >> 2) & 1)) * YZ + (t.j0 + ((n >> 1) & 1)) * P.Z + (t.k0 + (n & 1));
+        int sidx = (int)((unsigned)key * 2654435761u >> 24);     // H = 256
+        bool placed = false;
+        for (int probes = 0; probes < 16; ++probes) {
+          const int prev = atomicCAS(&L.keys[sidx], -1, key);
+          if (prev == -1 || prev == key) { placed = true; break; }
+          sidx = (sidx + 1) & (H - 1);
+        }
+        if (placed) {
+          slot[q] = sidx;
+          tick[q] = atomicAdd(&L.cnts[sidx], 1);
+          wq[q] = w;
+        } else {
+          float* dst = grad_k0 + (int64_t)key * C;
+          const float* gs = reinterpret_cast<const float*>(gv);
+#pragma unroll
+          for (int c = 0; c < C; ++c) atomicAdd(dst + c, w * gs[c]);
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    // ---- B: occupied-slot list + exclusive scan of the reference counters
+    int cnt = 0, run = 0;
+#pragma unroll
+    for (int it = 0; it < H / 64; ++it) {
+      const int s = it * 64 + lane;
+      const int c = L.cnts[s];
+      const unsigned long long bal = __ballot(c > 0);
+      int inc = c;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(inc, d);
+        if (lane >= d) inc += o;
+      }
+      if (c > 0) {
+        L.list[cnt + __popcll(bal & lt)] = s;
+        L.offs[s] = run + inc - c;
+      }
+      run += __builtin_amdgcn_readlane(inc, 63);
+      cnt += __popcll(bal);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    // ---- C: references to their sorted position
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (slot[q] >= 0) {
+        const int idx = L.offs[slot[q]] + tick[q];
+        L.ref_w[idx] = wq[q];
+        L.ref_s[idx] = sl;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    // ---- D: owner computes, one global atomic per (corner, channel)
+    for (int r0 = 0; r0 < cnt; r0 += RPI) {
+      const int row = r0 + rsub;
+      if (rsub < RPI && row < cnt) {
+        const int s = L.list[row];
+        const int key = L.keys[s];
+        const int beg = L.offs[s], n = L.cnts[s];
+        float acc = 0.0f;
+        for (int t = 0; t < n; ++t) acc = fmaf(L.ref_w[beg + t], L.g[L.ref_s[beg + t]][ch], acc);
+        atomicAdd(grad_k0 + (int64_t)key * C + ch, acc);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    for (int r = lane; r < cnt; r += 64) { const int s = L.list[r]; L.keys[s] = -1; L.cnts[s] = 0; }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  }
+}
+
+// ----------------------------------------------------------------------------------
 // march_density_bwd: one wavefront per ray, rec2 chunks walked from the far end.
 //   K13 (render_utils_kernel.cu:521-530): g_alpha = g_w*T - acc/((1-alpha)+1e-10), acc += g_w*w
 //   K10 (:402-405) raw2alpha backward, then the 8-corner scatter into grad_density.
 // ----------------------------------------------------------------------------------
+// DEDUP: the 8 x 64 corner contributions of a chunk are first merged in a per-wave LDS hash table
+// (single channel: ds_add_f32 on the slot is cheap here) and each distinct voxel is emitted once.
+template <bool DEDUP>
 __global__ void __launch_bounds__(DVGO_BLOCK)
 march_density_bwd_kernel(const dvgo_rec2_t* __restrict__ rec2, const int32_t* __restrict__ n2,
                          const int64_t* __restrict__ n_steps, const int64_t* __restrict__ cum,
@@ -308,11 +462,20 @@ march_density_bwd_kernel(const dvgo_rec2_t* __restrict__ rec2, const int32_t* __
                          MarchParams P, const float* __restrict__ alphainv_last,
                          const float* __restrict__ grad_weights, const float* __restrict__ grad_last,
                          float* __restrict__ grad_density) {
+  constexpr int H = 512;
+  __shared__ int s_keys[DEDUP ? 4 : 1][DEDUP ? H : 1];
+  __shared__ float s_vals[DEDUP ? 4 : 1][DEDUP ? H : 1];
   const int64_t ray = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   if (ray >= n_rays) return;
   const int c2 = __builtin_amdgcn_readfirstlane(n2[ray]);
   if (c2 == 0) return;
+  int* keys = s_keys[DEDUP ? (threadIdx.x >> 6) : 0];
+  float* vals = s_vals[DEDUP ? (threadIdx.x >> 6) : 0];
+  if (DEDUP) {
+    for (int s = lane; s < H; s += 64) { keys[s] = -1; vals[s] = 0.0f; }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  }
   const int64_t cs0 = rec_base(cum, n_steps, rec_stride, ray);
   const int64_t o3 = off3[ray];
   int c3_rem = (int)(off3[ray + 1] - o3);
@@ -357,9 +520,37 @@ march_density_bwd_kernel(const dvgo_rec2_t* __restrict__ rec2, const int32_t* __
           if (!dvgo_tri_inb(t, c, P.X, P.Y, P.Z)) continue;
           const int64_t off = (int64_t)(t.i0 + ((c >> 2) & 1)) * YZ + (int64_t)(t.j0 + ((c >> 1) & 1)) * P.Z +
                               (t.k0 + (c & 1));
-          atomicAdd(grad_density + off, dvgo_tri_weight(t, c) * g_d);
+          const float v = dvgo_tri_weight(t, c) * g_d;
+          if (DEDUP) {
+            const int key = (int)off;
+            int sidx = (int)((unsigned)key * 2654435761u >> 23);     // H = 512
+            bool placed = false;
+            for (int probes = 0; probes < 16; ++probes) {
+              const int prev = atomicCAS(&keys[sidx], -1, key);
+              if (prev == -1 || prev == key) { placed = true; break; }
+              sidx = (sidx + 1) & (H - 1);
+            }
+            if (placed) atomicAdd(&vals[sidx], v);
+            else atomicAdd(grad_density + off, v);
+          } else {
+            atomicAdd(grad_density + off, v);
+          }
         }
       }
+    }
+    if (DEDUP) {
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+#pragma unroll
+      for (int it = 0; it < H / 64; ++it) {
+        const int s = it * 64 + lane;
+        const int k = keys[s];
+        if (k != -1) {
+          atomicAdd(grad_density + k, vals[s]);
+          keys[s] = -1;
+          vals[s] = 0.0f;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     }
   }
 }
@@ -380,6 +571,12 @@ static MarchParams make_params(const float* mn, const float* mx, float stepdist,
 }
 
 extern "C" {
+
+int dvgo_set_tuning(int key, int value) {
+  if (key < 0 || key >= DVGO_TUNE_COUNT) return DVGO_EINVAL;
+  g_tuning[key] = value;
+  return 0;
+}
 
 // NOTE: xyz_min / xyz_max / xyz2ijk_scale / xyz2ijk_shift are HOST pointers (3 floats each)
 // in the fused entry points: they are model constants and travel as kernel arguments.
@@ -477,8 +674,21 @@ int dvgo_march_feat_bwd(const float* grad_feat, const int64_t* ray_id, const int
     return DVGO_EINVAL;
   if (!dvgo_fits(M3 * C)) return DVGO_ERANGE;
   const MarchParams P = make_params(xyz_min, xyz_max, stepdist, nullptr, nullptr, 0, 0, 0, X, Y, Z, 0.f, 0.f, 0.f);
-  march_feat_bwd_kernel<<<dvgo_blocks(M3 * C, DVGO_BLOCK), DVGO_BLOCK, 0, (hipStream_t)stream>>>(
-      grad_feat, ray_id, step_id, M3, rays_start, rays_dir, P, C, sC, sX, sY, sZ, grad_k0);
+  hipStream_t s = (hipStream_t)stream;
+  const int variant = g_tuning[DVGO_TUNE_FEAT_BWD];
+  const bool dense_cl = (sC == 1) && (sZ == C) && (sY == (int64_t)Z * C) && (sX == (int64_t)Y * Z * C) &&
+                        ((int64_t)X * Y * Z < ((int64_t)1 << 31)) && ((((uintptr_t)grad_feat) & 15) == 0);
+  if (variant == 1 && dense_cl && (C == 12 || C == 4 || C == 8 || C == 16)) {
+    const int64_t n_pass = (M3 + 31) / 32;
+    const int blocks = (int)((n_pass + 3) / 4 < 4096 ? (n_pass + 3) / 4 : 4096);
+    if (C == 12) march_feat_bwd_dedup_kernel<12><<<blocks, DVGO_BLOCK, 0, s>>>(grad_feat, ray_id, step_id, M3, rays_start, rays_dir, P, grad_k0);
+    else if (C == 4) march_feat_bwd_dedup_kernel<4><<<blocks, DVGO_BLOCK, 0, s>>>(grad_feat, ray_id, step_id, M3, rays_start, rays_dir, P, grad_k0);
+    else if (C == 8) march_feat_bwd_dedup_kernel<8><<<blocks, DVGO_BLOCK, 0, s>>>(grad_feat, ray_id, step_id, M3, rays_start, rays_dir, P, grad_k0);
+    else march_feat_bwd_dedup_kernel<16><<<blocks, DVGO_BLOCK, 0, s>>>(grad_feat, ray_id, step_id, M3, rays_start, rays_dir, P, grad_k0);
+  } else {
+    march_feat_bwd_kernel<<<dvgo_blocks(M3 * C, DVGO_BLOCK), DVGO_BLOCK, 0, s>>>(
+        grad_feat, ray_id, step_id, M3, rays_start, rays_dir, P, C, sC, sX, sY, sZ, grad_k0);
+  }
   DVGO_LAUNCH_CHECK();
   return 0;
 }
@@ -498,9 +708,14 @@ int dvgo_march_density_bwd(const dvgo_rec2_t* rec2, const int32_t* n2, const int
   if (!dvgo_fits(n_rays * 64)) return DVGO_ERANGE;
   const MarchParams P = make_params(xyz_min, xyz_max, stepdist, nullptr, nullptr, 0, 0, 0, X, Y, Z, 0.f,
                                     interval, 0.f);
-  march_density_bwd_kernel<<<dvgo_blocks(n_rays * 64, DVGO_BLOCK), DVGO_BLOCK, 0, (hipStream_t)stream>>>(
-      rec2, n2, n_steps, n_steps_cumsum, rec_stride, off3, n_rays, rays_start, rays_dir, P, alphainv_last,
-      grad_weights, grad_last, grad_density);
+  if (g_tuning[DVGO_TUNE_DENSITY_BWD] == 1 && (int64_t)X * Y * Z < ((int64_t)1 << 31))
+    march_density_bwd_kernel<true><<<dvgo_blocks(n_rays * 64, DVGO_BLOCK), DVGO_BLOCK, 0, (hipStream_t)stream>>>(
+        rec2, n2, n_steps, n_steps_cumsum, rec_stride, off3, n_rays, rays_start, rays_dir, P, alphainv_last,
+        grad_weights, grad_last, grad_density);
+  else
+    march_density_bwd_kernel<false><<<dvgo_blocks(n_rays * 64, DVGO_BLOCK), DVGO_BLOCK, 0, (hipStream_t)stream>>>(
+        rec2, n2, n_steps, n_steps_cumsum, rec_stride, off3, n_rays, rays_start, rays_dir, P, alphainv_last,
+        grad_weights, grad_last, grad_density);
   DVGO_LAUNCH_CHECK();
   return 0;
 }

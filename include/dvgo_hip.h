@@ -37,6 +37,13 @@ extern "C" {
 /* version of this ABI; bumped on any signature change */
 int dvgo_abi_version(void);
 
+/* Kernel-variant selection for A/B measurements (process-global; defaults are the fastest
+ * measured variants).  key: one of DVGO_TUNE_*; returns DVGO_EINVAL for an unknown key. */
+#define DVGO_TUNE_FEAT_BWD    0   /* 0 = one atomic per (sample,corner,channel); 1 = LDS de-duplicated rows */
+#define DVGO_TUNE_DENSITY_BWD 1   /* 0 = direct atomics; 1 = LDS de-duplicated */
+#define DVGO_TUNE_COUNT       8
+int dvgo_set_tuning(int key, int value);
+
 /* ---------------------------------------------------------------------------------
  * Sampling helpers.  render_utils.cpp:44-65 / render_utils_kernel.cu:11-132 (K1-K3)
  * --------------------------------------------------------------------------------- */
