@@ -23,6 +23,21 @@ __device__ __forceinline__ unsigned long long lanemask_lt(int lane) {
   return (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 }
 
+// distance of sample `step` along its ray:
+//   K6 (render_utils_kernel.cu:178)  stepdist * i_step          -- rays_start / unit rays_dir
+//   K7 (render_utils_kernel.cu:254)  (float)i_step / (N_samples - 1)  -- rays_o / un-normalised rays_d
+__device__ __forceinline__ float march_dist(float stepdist, int step) {
+  return (stepdist > 0.0f) ? stepdist * (float)step : ((float)step) / (-stepdist);
+}
+
+__device__ __forceinline__ void march_pos(const float* __restrict__ start, const float* __restrict__ dir, int64_t r,
+                                          float stepdist, int step, float& px, float& py, float& pz) {
+  const float dist = march_dist(stepdist, step);
+  px = fmaf(dir[3 * r + 0], dist, start[3 * r + 0]);
+  py = fmaf(dir[3 * r + 1], dist, start[3 * r + 1]);
+  pz = fmaf(dir[3 * r + 2], dist, start[3 * r + 2]);
+}
+
 // inclusive product scan across the wave
 __device__ __forceinline__ float wave_prod_scan(float v, int lane) {
 #pragma unroll
@@ -60,7 +75,7 @@ static int g_tuning[DVGO_TUNE_COUNT] = {1, 1, 0, 0, 0, 0, 0, 0};
 
 struct MarchParams {
   float mnx, mny, mnz, mxx, mxy, mxz;
-  float stepdist;
+  float stepdist;          // > 0: metric step (K6); < 0: NDC spacing, dist = step / (-stepdist) (K7)
   float scx, scy, scz, shx, shy, shz;   // xyz2ijk scale / shift
   int mX, mY, mZ;
   int X, Y, Z;
@@ -90,7 +105,7 @@ march_density_kernel(const float* __restrict__ rays_start, const float* __restri
   for (int base = 0; base < ns; base += 64) {
     const int step = base + lane;
     const bool act = step < ns;
-    const float dist = P.stepdist * (float)step;
+    const float dist = march_dist(P.stepdist, step);
     const float px = fmaf(dx, dist, sx), py = fmaf(dy, dist, sy), pz = fmaf(dz, dist, sz);
     bool keep = act && !((P.mnx > px) | (P.mny > py) | (P.mnz > pz) | (P.mxx < px) | (P.mxy < py) | (P.mxz < pz));
     if (mask != nullptr && keep) {
@@ -174,7 +189,7 @@ march_gather_kernel(const dvgo_rec3_t* __restrict__ rec3, const int64_t* __restr
   weights[i] = rec.weight;
   alpha[i] = rec.alpha;
   float px, py, pz;
-  dvgo_sample_pos(rays_start, rays_dir, r, P.stepdist, rec.step, px, py, pz);
+  march_pos(rays_start, rays_dir, r, P.stepdist, rec.step, px, py, pz);
   const TriSetup t = dvgo_tri_setup(px, py, pz, P.mnx, P.mny, P.mnz, P.mxx, P.mxy, P.mxz, P.X, P.Y, P.Z);
   float w[8];
   int64_t off[8];
@@ -288,7 +303,7 @@ march_feat_bwd_kernel(const float* __restrict__ grad_feat, const int64_t* __rest
   const int64_t i = tid / C;
   const int c = (int)(tid - i * C);
   float px, py, pz;
-  dvgo_sample_pos(rays_start, rays_dir, ray_id[i], P.stepdist, (int)step_id[i], px, py, pz);
+  march_pos(rays_start, rays_dir, ray_id[i], P.stepdist, (int)step_id[i], px, py, pz);
   const TriSetup t = dvgo_tri_setup(px, py, pz, P.mnx, P.mny, P.mnz, P.mxx, P.mxy, P.mxz, P.X, P.Y, P.Z);
   const float g = grad_feat[tid];
 #pragma unroll
@@ -359,7 +374,7 @@ march_feat_bwd_dedup_kernel(const float* __restrict__ grad_feat, const int64_t* 
     // ---- A: table insert + tickets
     if (i < M3) {
       float px, py, pz;
-      dvgo_sample_pos(rays_start, rays_dir, ray_id[i], P.stepdist, (int)step_id[i], px, py, pz);
+      march_pos(rays_start, rays_dir, ray_id[i], P.stepdist, (int)step_id[i], px, py, pz);
       const TriSetup t = dvgo_tri_setup(px, py, pz, P.mnx, P.mny, P.mnz, P.mxx, P.mxy, P.mxz, P.X, P.Y, P.Z);
       const float4* gp = reinterpret_cast<const float4*>(grad_feat + i * C);
       float4 gv[C / 4];
@@ -511,7 +526,7 @@ march_density_bwd_kernel(const dvgo_rec2_t* __restrict__ rec2, const int32_t* __
       v = v * (double)P.interval;
       v = v * (double)g_alpha;
       const float g_d = (float)v;
-      const float dist = P.stepdist * (float)step;
+      const float dist = march_dist(P.stepdist, step);
       const float px = fmaf(dx, dist, sx), py = fmaf(dy, dist, sy), pz = fmaf(dz, dist, sz);
       const TriSetup t = dvgo_tri_setup(px, py, pz, P.mnx, P.mny, P.mnz, P.mxx, P.mxy, P.mxz, P.X, P.Y, P.Z);
       if (g_d != 0.0f) {

@@ -31,6 +31,50 @@ def _as_f32(x):
                            dtype=torch.float32)
 
 
+class _LinearSplitK(torch.autograd.Function):
+    """y = x @ W^T + b for tall-skinny x [M, K] (M ~ 10^6 samples, K, N <= 128).
+
+    Same maths as nn.Linear; only the weight gradient is evaluated differently: dW = g^T x is a
+    reduction over the M samples into a tiny [N, K] output, for which the stock GEMM picks a
+    3-ms single-pass kernel at M = 2 M (profiles/r1).  Here the samples are cut into chunks that are
+    reduced as one batched GEMM (parallel over chunks) and then summed."""
+    CHUNK = 8192
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        return torch.addmm(bias, x, weight.t())
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        g = g.contiguous()
+        gx = g @ weight if ctx.needs_input_grad[0] else None
+        M, chunk = x.shape[0], _LinearSplitK.CHUNK
+        main = (M // chunk) * chunk
+        gw = None
+        if main:
+            S = main // chunk
+            gw = torch.bmm(g[:main].view(S, chunk, -1).transpose(1, 2), x[:main].view(S, chunk, -1)).sum(0)
+        if main < M:
+            tail = g[main:].t() @ x[main:]
+            gw = tail if gw is None else gw + tail
+        return gx, gw, g.sum(0)
+
+
+def mlp_forward(net, x):
+    """Run an rgbnet (nn.Sequential of Linear / ReLU / nested Sequential) with the split-K linear for
+    large sample counts; identical module tree and parameters."""
+    for mod in net:
+        if isinstance(mod, nn.Sequential):
+            x = mlp_forward(mod, x)
+        elif isinstance(mod, nn.Linear) and x.shape[0] >= 4 * _LinearSplitK.CHUNK and x.requires_grad | mod.weight.requires_grad:
+            x = _LinearSplitK.apply(x.contiguous(), mod.weight, mod.bias)
+        else:
+            x = mod(x)
+    return x
+
+
 def make_rgbnet(dim0, width, depth):
     """Same module tree (hence state_dict keys) as lib/dvgo.py:123-131."""
     net = nn.Sequential(
@@ -263,7 +307,7 @@ class DirectVoxGO(nn.Module):
         viewdirs_emb = (viewdirs.unsqueeze(-1) * self.viewfreq).flatten(-2)
         viewdirs_emb = torch.cat([viewdirs, viewdirs_emb.sin(), viewdirs_emb.cos()], -1)
         viewdirs_emb = viewdirs_emb.flatten(0, -2)[ray_id]
-        rgb_logit = self.rgbnet(torch.cat([k0_view, viewdirs_emb], -1))
+        rgb_logit = mlp_forward(self.rgbnet, torch.cat([k0_view, viewdirs_emb], -1))
         if self.rgbnet_direct:
             return torch.sigmoid(rgb_logit)
         return torch.sigmoid(rgb_logit + k0_diffuse)

@@ -31,7 +31,7 @@ class MarchConfig:
     kernels as kernel arguments, so they are kept as host arrays here)."""
 
     def __init__(self, xyz_min, xyz_max, stepdist, act_shift, interval, fast_color_thres, near, far,
-                 mask=None, xyz2ijk_scale=None, xyz2ijk_shift=None):
+                 mask=None, xyz2ijk_scale=None, xyz2ijk_shift=None, ndc_samples=0):
         self.xyz_min_t, self.xyz_max_t = xyz_min, xyz_max          # device tensors (prepare kernel)
         self.xyz_min_h, self.xyz_max_h = f3(xyz_min), f3(xyz_max)  # host copies (fused kernels)
         self.stepdist = float(stepdist)
@@ -39,6 +39,11 @@ class MarchConfig:
         self.interval = float(interval)
         self.thres = float(fast_color_thres)
         self.near, self.far = float(near), float(far)
+        # > 0: forward-facing / MPI sampling (lib/dmpigo.py:173-198): every ray has exactly ndc_samples
+        # samples at o + d * s/(ndc_samples-1); encoded for the kernels as stepdist = -(ndc_samples-1)
+        self.ndc_samples = int(ndc_samples)
+        if self.ndc_samples > 0:
+            self.stepdist = -float(self.ndc_samples - 1)
         self.mask = mask
         self.scale_h = f3(xyz2ijk_scale) if mask is not None else f3([0, 0, 0])
         self.shift_h = f3(xyz2ijk_shift) if mask is not None else f3([0, 0, 0])
@@ -72,22 +77,28 @@ class _FusedMarch(torch.autograd.Function):
         C, kX, kY, kZ, sC, sX, sY, sZ = _grid_geom(k0)
         assert (kX, kY, kZ) == (X, Y, Z), 'density and k0 must share world_size'
         st = stream_of(rays_o)
-        stride = _rec_stride(cfg, N)
+        ndc = cfg.ndc_samples > 0
+        stride = cfg.ndc_samples if ndc else _rec_stride(cfg, N)
 
-        t_min = torch.empty(N, dtype=torch.float32, device=dev)
-        t_max = torch.empty_like(t_min)
-        n_steps = torch.empty(N, dtype=torch.int64, device=dev)
-        start = torch.empty((N, 3), dtype=torch.float32, device=dev)
-        dirs = torch.empty((N, 3), dtype=torch.float32, device=dev)
+        if ndc:
+            n_steps = torch.full((N,), cfg.ndc_samples, dtype=torch.int64, device=dev)
+            start, dirs = rays_o, rays_d
+        else:
+            t_min = torch.empty(N, dtype=torch.float32, device=dev)
+            t_max = torch.empty_like(t_min)
+            n_steps = torch.empty(N, dtype=torch.int64, device=dev)
+            start = torch.empty((N, 3), dtype=torch.float32, device=dev)
+            dirs = torch.empty((N, 3), dtype=torch.float32, device=dev)
         cum = torch.empty(N, dtype=torch.int64, device=dev) if stride == 0 else None
         n2 = torch.empty(N, dtype=torch.int32, device=dev)
         n3 = torch.empty(N, dtype=torch.int32, device=dev)
         last = torch.empty(N, dtype=torch.float32, device=dev)
         off3 = torch.empty(N + 1, dtype=torch.int64, device=dev)
         with torch.cuda.device_of(rays_o):
-            L.call('dvgo_sample_pts_prepare', ptr(rays_o), ptr(rays_d), ptr(cfg.xyz_min_t), ptr(cfg.xyz_max_t),
-                   _flt(cfg.near), _flt(cfg.far), _flt(cfg.stepdist), _i64(N), ptr(t_min), ptr(t_max),
-                   ptr(n_steps), ptr(cum), ptr(start), ptr(dirs), st)
+            if not ndc:
+                L.call('dvgo_sample_pts_prepare', ptr(rays_o), ptr(rays_d), ptr(cfg.xyz_min_t), ptr(cfg.xyz_max_t),
+                       _flt(cfg.near), _flt(cfg.far), _flt(cfg.stepdist), _i64(N), ptr(t_min), ptr(t_max),
+                       ptr(n_steps), ptr(cum), ptr(start), ptr(dirs), st)
             if stride == 0:
                 cap = int(cum[-1].item()) if N > 0 else 0     # exact layout: one extra host read
             else:

@@ -60,7 +60,7 @@ def lego_like_rays(n_rays, gen, n_views=100, H=800, W=800, focal=1111.11, radius
     return ro, rd, vd
 
 
-def blob_density(ws, xyz_min, xyz_max, gen, amp=12.0, bias=-4.0, noise=1.5, radius=0.9):
+def blob_density(ws, xyz_min, xyz_max, gen, amp=16.0, bias=-9.0, noise=1.5, radius=0.9):
     ax = [torch.linspace(float(xyz_min[a]), float(xyz_max[a]), ws[a]) for a in range(3)]
     xx, yy, zz = torch.meshgrid(*ax, indexing='ij')
     r = torch.sqrt(xx ** 2 + yy ** 2 + zz ** 2) / radius

@@ -164,6 +164,11 @@ int dvgo_segment_sum(const float* src, const int64_t* index, int64_t M, int C,
  * In the dvgo_march_* entry points xyz_min, xyz_max, xyz2ijk_scale and xyz2ijk_shift are
  * HOST pointers to 3 floats (model constants; they travel as kernel arguments).
  *
+ * `stepdist` > 0 : metric spacing, sample s of ray r sits at rays_start[r] + rays_dir[r]*(stepdist*s)
+ *                  (K6, render_utils_kernel.cu:178-181; rays_start/rays_dir from dvgo_sample_pts_prepare).
+ * `stepdist` < 0 : NDC / MPI spacing with N_samples-1 = -stepdist: rays_o[r] + rays_d[r]*((float)s/(N_samples-1))
+ *                  (K7, render_utils_kernel.cu:254-257; pass rays_o / rays_d and n_steps[r] = N_samples).
+ *
  * Scratch records.  Each ray owns a slice of the rec2/rec3 scratch arrays that starts at
  *   n_steps_cumsum[r] - n_steps[r]   when n_steps_cumsum != NULL (exact, M0 records in total), or
  *   r * rec_stride                   when n_steps_cumsum == NULL (rec_stride >= max n_steps; since

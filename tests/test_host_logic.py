@@ -132,3 +132,40 @@ def test_compat_shim_binds_reference_modules_by_name(tmp_path):
     out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr[-2000:]
     assert 'ok (1, 1, 8, 8, 8)' in out.stdout
+
+
+def test_ray_generator_matches_reference_run():
+    """render.get_rays_of_a_view vs the reference's lib/ray_utils.py output (tests/golden/rays.npz)."""
+    from directvoxgo_amd.render import get_rays_of_a_view
+    from directvoxgo_amd.scenes import pose_spherical
+    g = load_golden('rays')
+    H, W, focal = int(g['H']), int(g['W']), float(g['focal'])
+    K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]], np.float32)
+    outs = [get_rays_of_a_view(H, W, K, pose_spherical(float(th), float(g['phi']), float(g['radius'])), ndc=False,
+                               inverse_y=False, flip_x=False, flip_y=False) for th in g['thetas']]
+    for k, name in enumerate(['rays_o', 'rays_d', 'viewdirs']):
+        got = torch.cat([o[k].reshape(-1, 3) for o in outs]).numpy()
+        np.testing.assert_allclose(got, g[name], atol=1e-6)
+
+
+def test_checkpoint_round_trip_in_reference_format(tmp_path):
+    """run.py:420-437 dict layout; grids stored contiguous; MaskCache(path=...) can read it."""
+    from directvoxgo_amd.checkpoint import load_model, save_checkpoint
+    from directvoxgo_amd.dvgo import DirectVoxGO
+    from directvoxgo_amd.ops import MaskCache
+    torch.manual_seed(0)
+    m = DirectVoxGO([-1, -1, -1], [1, 1, 1], num_voxels=9 ** 3, num_voxels_base=9 ** 3, alpha_init=1e-2,
+                    fast_color_thres=1e-4, rgbnet_dim=12, rgbnet_width=16)
+    with torch.no_grad():
+        m.density.normal_(); m.k0.normal_()
+    p = str(tmp_path / 'fine_last.tar')
+    save_checkpoint(p, m, None, 123)
+    ck = torch.load(p, weights_only=False)
+    assert set(ck) == {'global_step', 'model_kwargs', 'model_state_dict', 'optimizer_state_dict'}
+    assert ck['model_state_dict']['k0'].is_contiguous() and ck['global_step'] == 123
+    m2 = load_model(DirectVoxGO, p)
+    assert m2.k0.stride()[1] == 1
+    for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k
+    mc = MaskCache(path=p, mask_cache_thres=1e-3)
+    assert mc.mask.shape == (9, 9, 9)
