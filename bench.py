@@ -57,6 +57,21 @@ def algorithmic_bytes(name, N, M_d, M2, M_k, C, n_grid):
     }[name]
 
 
+def pmc_traffic(workload, world, n_rays):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*/pmc_traffic.json), when they
+    were collected for this exact workload; None otherwise."""
+    import glob
+    best = {}
+    for f in sorted(glob.glob(os.path.join(REPO, 'profiles', '*', 'pmc_traffic.json'))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get('workload') == workload and d.get('grid') == world and d.get('rays') == n_rays:
+            best = {k: v['hbm_bytes'] for k, v in d['kernels'].items()}
+    return best
+
+
 def build(workload, world, n_rays, device, seed):
     from directvoxgo_amd.dvgo import DirectVoxGO
     from directvoxgo_amd.scenes import roofline_scene, synthetic_scene
@@ -245,10 +260,13 @@ def main():
     march = {k: v for k, v in kernels.items() if k in ('dvgo_march_gather', 'dvgo_march_feat_bwd', 'dvgo_march_density',
                                                         'dvgo_march_density_bwd')}
     dom = max(march, key=lambda k: march[k]['avg_ms']) if march else None
+    traffic = pmc_traffic(args.workload, args.world, args.rays)
+    for k in kernels:
+        kernels[k]['traffic'] = traffic.get(k)
     roofline = None
     if dom:
         roofline = {'kernel': dom, 'bound': 'hbm', 'achieved': kernels[dom]['GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                    'frac': kernels[dom]['frac'], 'traffic': None, 'alg_bytes_per_launch': kernels[dom]['alg_bytes'],
+                    'frac': kernels[dom]['frac'], 'traffic': traffic.get(dom), 'alg_bytes_per_launch': kernels[dom]['alg_bytes'],
                     'avg_launch_ms': kernels[dom]['avg_ms']}
 
     out = {
