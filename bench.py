@@ -215,19 +215,25 @@ def main():
     ap.add_argument('--no-secondary', action='store_true', help='skip the lego-like secondary measurement')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-rays', type=int, default=512)
+    ap.add_argument('--backend', default='nccl', help="torch.distributed backend for N > 1 ('nccl' = RCCL on ROCm)")
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1:
+    n_dev = torch.cuda.device_count()
+    dev_index = local_rank % max(n_dev, 1) if world > 1 else 0       # one rank per GPU; the modulo only matters
+    if world > 1:                                                     # when rehearsing several ranks on one GPU (gloo)
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        torch.cuda.set_device(dev_index)
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', dev_index))
+        else:
+            dist.init_process_group(args.backend)
     else:
         torch.cuda.set_device(0)
     assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
-    device = torch.device('cuda', local_rank if world > 1 else 0)
+    device = torch.device('cuda', dev_index)
 
     from directvoxgo_amd.train import FINE_TRAIN, TrainStep
 
