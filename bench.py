@@ -38,7 +38,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/
 
 HOT_KERNELS = ['dvgo_sample_pts_prepare', 'dvgo_march_density', 'dvgo_exclusive_scan_i32', 'dvgo_march_gather',
                'dvgo_march_composite', 'dvgo_march_composite_bwd', 'dvgo_march_feat_bwd', 'dvgo_march_density_bwd',
-               'dvgo_adam_upd']
+               'dvgo_adam_upd', 'dvgo_shade_fwd', 'dvgo_shade_bwd', 'dvgo_shade_wgrad']
 
 
 def algorithmic_bytes(name, N, M_d, M2, M_k, C, n_grid):
@@ -54,6 +54,10 @@ def algorithmic_bytes(name, N, M_d, M2, M_k, C, n_grid):
         'dvgo_march_feat_bwd': M_k * (8 * C * 4 + C * 4),                   # each atomic counted once as 4 B
         'dvgo_march_density_bwd': M2 * (8 * 4 + 16),
         'dvgo_adam_upd': None,                                              # per call: 28 B / element (dense)
+        # colour head (row N3): MFMA-bound, bytes listed for completeness (features / activations in and out)
+        'dvgo_shade_fwd': M_k * (C * 4 + 8 + 12 + 2 * 512),
+        'dvgo_shade_bwd': M_k * (24 + 4 * 512 + C * 4),
+        'dvgo_shade_wgrad': M_k * (4 * 512 + C * 4 + 12),
     }[name]
 
 

@@ -1,0 +1,526 @@
+// Fused colour head ("rgbnet") for gfx950 -- row N3 of SURVEY.md section 8f.
+//
+// Replaces, for the fine-stage model (/root/reference/lib/dvgo.py:516-541):
+//   viewdirs_emb[ray_id] gather, cat([k0_view, viewdirs_emb]), Linear(D_in,W)+ReLU, Linear(W,W)+ReLU,
+//   Linear(W,3), (+ k0_diffuse), sigmoid
+// i.e. three skinny fp32 GEMMs (M ~ 2 M rows, N <= 128) plus five element-wise passes over [M,W].
+//
+// This is the one dense contraction of the path, so it is the one place MFMA applies.  It stays in
+// fp32 (the reference runs the MLP in fp32; bf16 would break the stated tolerances): gfx950's
+// v_mfma_f32_32x32x2_f32 is an exact fp32 FMA chain at the vector-FMA rate and needs ONE VGPR per
+// operand per lane.
+//
+// Layout trick (no LDS transposes between layers): every layer is computed TRANSPOSED,
+//   H^T[f][row] = sum_k W[f][k] * X^T[k][row],
+// with the weights as the MFMA A operand and the activations as the B operand.  The 32x32 result tile
+// then has `row` on the lane (col = lane & 31) and the output features on the 16 registers
+// (f = (r&3) + 8*(r>>2) + 4*(lane>>5)).  A B operand needs B[k = 2s + (lane>>5)][col = lane & 31]:
+// register r of the previous layer's tile already IS such an operand for the feature pair
+// {f(r,0), f(r,1)}, as long as the A operand of that k-step is W[f_out][f(r, lane>>5)] -- the k order
+// inside a contraction is free.  So the weights are stored in LDS pre-permuted to that order (once
+// per workgroup) and the activations never leave their registers.
+// Layer 3 (3 outputs) is 192 VALU FMAs per lane plus one cross-half add.
+#include "common.h"
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+// Saved activations / gradients are plain row-major [M, features]: in the accumulator layout a lane owns
+// 4 consecutive features per register quad, i.e. one 16-byte piece of its row.
+// one workgroup per CU (the permuted weights take 86 KB of LDS); 8 wavefronts = 2 per SIMD
+#define SHADE_THREADS 512
+#define SHADE_WAVES (SHADE_THREADS / 64)
+
+template <int WIDTH, int S1>
+struct ShadeLds {
+  static constexpr int T = WIDTH / 32;
+  float w1a[T][S1][64];        // [out tile][k-step][lane]   A operand of layer 1
+  float w2a[T][T][16][64];     // [out tile][in tile][reg][lane]  A operand of layer 2
+  float w3p[3][2][T * 16];     // [c][lane half][in tile*16 + reg]
+  float b1p[2][T * 16];        // accumulator-layout biases
+  float b2p[2][T * 16];
+  float b3[4];
+};
+
+__device__ __forceinline__ int acc_feature(int t, int r, int h) { return 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+template <int WIDTH, int S1>
+__device__ __forceinline__ void shade_load_weights(ShadeLds<WIDTH, S1>& L, const float* __restrict__ W1,
+                                                   const float* __restrict__ b1, const float* __restrict__ W2,
+                                                   const float* __restrict__ b2, const float* __restrict__ W3,
+                                                   const float* __restrict__ b3, int D_in) {
+  constexpr int T = WIDTH / 32;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int i = tid; i < T * S1 * 64; i += nt) {
+    const int l = i & 63, s = (i >> 6) % S1, t = (i >> 6) / S1;
+    const int k = 2 * s + (l >> 5);
+    (&L.w1a[0][0][0])[i] = (k < D_in) ? W1[(32 * t + (l & 31)) * D_in + k] : 0.0f;
+  }
+  for (int i = tid; i < T * T * 16 * 64; i += nt) {
+    const int l = i & 63, r = (i >> 6) & 15, t = (i >> 10) % T, t2 = (i >> 10) / T;
+    (&L.w2a[0][0][0][0])[i] = W2[(32 * t2 + (l & 31)) * WIDTH + acc_feature(t, r, l >> 5)];
+  }
+  for (int i = tid; i < 3 * 2 * T * 16; i += nt) {
+    const int tr = i % (T * 16), h = (i / (T * 16)) & 1, c = i / (2 * T * 16);
+    (&L.w3p[0][0][0])[i] = W3[c * WIDTH + acc_feature(tr >> 4, tr & 15, h)];
+  }
+  for (int i = tid; i < 2 * T * 16; i += nt) {
+    const int tr = i % (T * 16), h = i / (T * 16);
+    const int f = acc_feature(tr >> 4, tr & 15, h);
+    (&L.b1p[0][0])[i] = b1[f];
+    (&L.b2p[0][0])[i] = b2[f];
+  }
+  if (tid < 3) L.b3[tid] = b3[tid];
+}
+
+// forward of one 32-row tile.  Layer 1 keeps all WIDTH features (T accumulator tiles) because every
+// layer-2 output needs them; layer 2 is walked one 32-feature output tile at a time and each tile is
+// consumed immediately (optional H2 store + its share of the three layer-3 dot products), so only
+// T + 1 accumulator tiles are live and two waves fit on a SIMD.
+// Returns the three logits (before the optional diffuse term and the sigmoid) in z[3], valid on every
+// lane; acc1 holds the post-ReLU layer-1 activations.
+template <int WIDTH, int S1>
+__device__ __forceinline__ void shade_tile_forward(const ShadeLds<WIDTH, S1>& L, const float (&x)[S1], int lane,
+                                                   f32x16 (&acc1)[WIDTH / 32], float (&z)[3],
+                                                   float* __restrict__ H2row /* H2 + row*WIDTH or nullptr */) {
+  constexpr int T = WIDTH / 32;
+  const int h = lane >> 5;
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc1[t][r] = L.b1p[h][t * 16 + r];
+#pragma unroll
+    for (int s = 0; s < S1; ++s) acc1[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(L.w1a[t][s][lane], x[s], acc1[t], 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc1[t][r] = fmaxf(acc1[t][r], 0.0f);
+  }
+  float p[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll 1      // keeps the scheduler from hoisting every tile's LDS reads (and spilling)
+  for (int t2 = 0; t2 < T; ++t2) {
+    f32x16 acc2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[r] = L.b2p[h][t2 * 16 + r];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(L.w2a[t2][t][r][lane], acc1[t][r], acc2, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[r] = fmaxf(acc2[r], 0.0f);
+    if (H2row != nullptr) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4*>(H2row + 32 * t2 + 8 * q + 4 * h) =
+            make_float4(acc2[4 * q], acc2[4 * q + 1], acc2[4 * q + 2], acc2[4 * q + 3]);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) p[c] = fmaf(L.w3p[c][h][t2 * 16 + r], acc2[r], p[c]);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) z[c] = p[c] + __shfl_xor(p[c], 32) + L.b3[c];
+}
+
+// X^T operand of layer 1 for this lane: x[s] = input feature k = 2s + (lane>>5) of row (lane & 31):
+//   k < n_view           : feat[row, c_view0 + k]          (k0_view,  lib/dvgo.py:518-523)
+//   k < n_view + E       : emb[ray_id[row], k - n_view]    (viewdirs_emb[ray_id], lib/dvgo.py:524-526)
+template <int S1>
+__device__ __forceinline__ void shade_load_x(const float* __restrict__ feat, int C, int c_view0, int n_view,
+                                             const float* __restrict__ emb, int E, int64_t row, int64_t ray,
+                                             int lane, float (&x)[S1]) {
+  const int h = lane >> 5;
+  const float* fr = feat + row * C + c_view0;
+  const float* er = emb + ray * E - n_view;
+#pragma unroll
+  for (int s = 0; s < S1; ++s) {
+    const int k = 2 * s + h;
+    float v = 0.0f;
+    if (k < n_view) v = fr[k];
+    else if (k < n_view + E) v = er[k];
+    x[s] = v;
+  }
+}
+
+template <int WIDTH, int S1, bool DIFFUSE>
+__global__ void __launch_bounds__(SHADE_THREADS)
+shade_fwd_kernel(const float* __restrict__ feat, int C, int c_view0, int n_view, const float* __restrict__ emb, int E,
+                 const int64_t* __restrict__ ray_id, int64_t M, const float* __restrict__ W1,
+                 const float* __restrict__ b1, const float* __restrict__ W2, const float* __restrict__ b2,
+                 const float* __restrict__ W3, const float* __restrict__ b3, int D_in, float* __restrict__ rgb,
+                 float* __restrict__ H1, float* __restrict__ H2) {
+  constexpr int T = WIDTH / 32;
+  __shared__ ShadeLds<WIDTH, S1> L;
+  shade_load_weights<WIDTH, S1>(L, W1, b1, W2, b2, W3, b3, D_in);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, h = lane >> 5;
+  const int64_t n_tiles = (M + 31) / 32;
+  const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t nw = (int64_t)gridDim.x * (blockDim.x >> 6);
+  for (int64_t tile = gw; tile < n_tiles; tile += nw) {
+    const int64_t row = tile * 32 + (lane & 31);
+    const bool valid = row < M;
+    const int64_t rowc = valid ? row : (M - 1);
+    float x[S1];
+    shade_load_x<S1>(feat, C, c_view0, n_view, emb, E, rowc, ray_id[rowc], lane, x);
+    f32x16 acc1[T];
+    float z[3];
+    const bool keep = valid && (H1 != nullptr);
+    shade_tile_forward<WIDTH, S1>(L, x, lane, acc1, z, keep ? (H2 + row * WIDTH) : nullptr);
+    if (valid) {
+      if (h == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float zz = DIFFUSE ? z[c] + feat[row * C + c] : z[c];
+          rgb[row * 3 + c] = 1.0f / (1.0f + expf(-zz));
+        }
+      }
+      if (H1 != nullptr) {     // training: keep the post-ReLU activations for the backward pass
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(H1 + row * WIDTH + 32 * t + 8 * q + 4 * h) =
+                make_float4(acc1[t][4 * q], acc1[t][4 * q + 1], acc1[t][4 * q + 2], acc1[t][4 * q + 3]);
+        }
+      }
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------
+// Backward, data-gradient part.  Per 32-row tile (activations H1/H2 saved by the training forward):
+//   gz  = g_rgb * rgb * (1 - rgb)                                  (sigmoid')
+//   G2  = (H2 > 0) * (W3^T gz)                   VALU, accumulator layout
+//   G1  = (H1 > 0) * (W2^T G2)                   MFMA, A = W2^T pre-permuted so that G2's registers are
+//                                                the B operands (same trick as the forward)
+//   gx  = W1[:, :32]^T G1                        MFMA, only the first 32 input features are produced
+//                                                (the feature-grid part; the view embedding needs no grad)
+// G1, G2 and gz are written out for the weight gradients (dW = G^T H, reductions over all samples,
+// done as split-K batched GEMMs by the caller); g_feat gets gz (diffuse) and gx.
+// ----------------------------------------------------------------------------------
+template <int WIDTH>
+struct ShadeBwdLds {
+  static constexpr int T = WIDTH / 32;
+  float w2ta[T][T][16][64];    // [in tile][out tile][reg][lane] = W2[f_out(t2,r,lane>>5)][32*t_in + (lane&31)]
+  float w1ta[T][16][64];       // [tile][reg][lane]              = W1[f(t,r,lane>>5)][lane&31]   (k < D_in else 0)
+  float w3p[3][2][T * 16];
+};
+
+template <int WIDTH, bool DIFFUSE>
+__global__ void __launch_bounds__(SHADE_THREADS)
+shade_bwd_kernel(const float* __restrict__ g_rgb, const float* __restrict__ rgb, const float* __restrict__ H1,
+                 const float* __restrict__ H2, int64_t M, const float* __restrict__ W1, const float* __restrict__ W2,
+                 const float* __restrict__ W3, int D_in, int C, int c_view0, int n_view,
+                 float* __restrict__ g_feat, float* __restrict__ G1, float* __restrict__ G2, float* __restrict__ gz_out) {
+  constexpr int T = WIDTH / 32;
+  __shared__ ShadeBwdLds<WIDTH> L;
+  {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int i = tid; i < T * T * 16 * 64; i += nt) {
+      const int l = i & 63, r = (i >> 6) & 15, t2 = (i >> 10) % T, tin = (i >> 10) / T;
+      (&L.w2ta[0][0][0][0])[i] = W2[acc_feature(t2, r, l >> 5) * WIDTH + 32 * tin + (l & 31)];
+    }
+    for (int i = tid; i < T * 16 * 64; i += nt) {
+      const int l = i & 63, r = (i >> 6) & 15, t = i >> 10;
+      const int k = l & 31;
+      (&L.w1ta[0][0][0])[i] = (k < D_in) ? W1[acc_feature(t, r, l >> 5) * D_in + k] : 0.0f;
+    }
+    for (int i = tid; i < 3 * 2 * T * 16; i += nt) {
+      const int tr = i % (T * 16), h = (i / (T * 16)) & 1, c = i / (2 * T * 16);
+      (&L.w3p[0][0][0])[i] = W3[c * WIDTH + acc_feature(tr >> 4, tr & 15, h)];
+    }
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, h = lane >> 5;
+  const int64_t n_tiles = (M + 31) / 32;
+  const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t nw = (int64_t)gridDim.x * (blockDim.x >> 6);
+  for (int64_t tile = gw; tile < n_tiles; tile += nw) {
+    const int64_t row = tile * 32 + (lane & 31);
+    const bool valid = row < M;
+    const int64_t rowc = valid ? row : (M - 1);
+    float gz[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float o = rgb[rowc * 3 + c];
+      gz[c] = valid ? g_rgb[rowc * 3 + c] * o * (1.0f - o) : 0.0f;
+    }
+    if (valid && h == 0) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        gz_out[row * 3 + c] = gz[c];
+        if (DIFFUSE) g_feat[row * C + c] = gz[c];
+      }
+    }
+    // G2 in accumulator layout (all T tiles stay live: they are the B operands below)
+    f32x16 g2[T];
+#pragma unroll
+    for (int t2 = 0; t2 < T; ++t2) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int f = 32 * t2 + 8 * q + 4 * h;
+        const float4 hv = *reinterpret_cast<const float4*>(H2 + rowc * WIDTH + f);
+        const float hh[4] = {hv.x, hv.y, hv.z, hv.w};
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * q + e;
+          const float v = fmaf(L.w3p[2][h][t2 * 16 + r], gz[2],
+                               fmaf(L.w3p[1][h][t2 * 16 + r], gz[1], L.w3p[0][h][t2 * 16 + r] * gz[0]));
+          o[e] = (hh[e] > 0.0f) ? v : 0.0f;          // gz == 0 on rows past M, so o == 0 there
+          g2[t2][r] = o[e];
+        }
+        if (valid) *reinterpret_cast<float4*>(G2 + row * WIDTH + f) = make_float4(o[0], o[1], o[2], o[3]);
+      }
+    }
+    f32x16 gx;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gx[r] = 0.0f;
+#pragma unroll 1
+    for (int tin = 0; tin < T; ++tin) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+      for (int t2 = 0; t2 < T; ++t2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(L.w2ta[tin][t2][r][lane], g2[t2][r], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int f = 32 * tin + 8 * q + 4 * h;
+        const float4 hv = *reinterpret_cast<const float4*>(H1 + rowc * WIDTH + f);
+        acc[4 * q + 0] = (hv.x > 0.0f) ? acc[4 * q + 0] : 0.0f;
+        acc[4 * q + 1] = (hv.y > 0.0f) ? acc[4 * q + 1] : 0.0f;
+        acc[4 * q + 2] = (hv.z > 0.0f) ? acc[4 * q + 2] : 0.0f;
+        acc[4 * q + 3] = (hv.w > 0.0f) ? acc[4 * q + 3] : 0.0f;
+        if (valid)
+          *reinterpret_cast<float4*>(G1 + row * WIDTH + f) =
+              make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        gx = __builtin_amdgcn_mfma_f32_32x32x2f32(L.w1ta[tin][r][lane], acc[r], gx, 0, 0, 0);
+    }
+    if (valid) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int k = (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (k < n_view) g_feat[row * C + c_view0 + k] = gx[r];
+      }
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------
+// Backward, weight-gradient part:  dW2 = G2^T H1,  dW1 = G1^T X,  dW3 = gz^T H2,  db = column sums.
+// All operands are row-major [M, features], and a contraction over ROWS wants exactly that:
+//   A[i = out feature][k = row]  : lane (i, h) reads G[row = 2s + h][f0 + i]
+//   B[k = row][j = in feature]   : lane (j, h) reads H[row = 2s + h][f0' + j]
+// i.e. consecutive lanes read consecutive floats of one row: no transpose anywhere.  Each 32-row tile
+// is staged once into LDS with 16-byte coalesced loads (software-prefetched one tile ahead) and the
+// MFMA operands are conflict-free ds_read_b32.
+// The 4 waves of a workgroup walk the SAME 32-row tiles and split the output features between them
+// (wave w owns out-feature tile w), which keeps every wave's persistent accumulators at 112 registers
+// (dW2: 4 tiles, dW1: 2 tiles, dW3: 1 tile); the B operands are shared through L1.
+// Each workgroup writes its partial sums to part[blockIdx]; the caller sums over workgroups.
+// ----------------------------------------------------------------------------------
+template <int WIDTH>
+struct ShadeWgradLds {
+  float g1[32][WIDTH], g2[32][WIDTH], h1[32][WIDTH], h2[32][WIDTH];
+  float x[32][64];
+  float gz[32][4];
+};
+
+template <int WIDTH>
+__global__ void __launch_bounds__(256)
+shade_wgrad_kernel(const float* __restrict__ G1, const float* __restrict__ G2, const float* __restrict__ gz,
+                   const float* __restrict__ H1, const float* __restrict__ H2, const float* __restrict__ feat, int C,
+                   int c_view0, int n_view, const float* __restrict__ emb, int E, const int64_t* __restrict__ ray_id,
+                   int64_t M, float* __restrict__ part /* [gridDim][WIDTH*WIDTH + WIDTH*64 + 32*WIDTH + 3*WIDTH] */) {
+  constexpr int T = WIDTH / 32;
+  static_assert(T == 4, "one out-feature tile per wave");
+  __shared__ __attribute__((aligned(16))) ShadeWgradLds<WIDTH> L;
+  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, j = lane & 31, w = tid >> 6;
+  f32x16 aW2[T], aW1[2], aW3;
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) aW2[t][r] = 0.0f;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) aW1[t][r] = 0.0f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) aW3[r] = 0.0f;
+  float sb1 = 0.0f, sb2 = 0.0f, sb3 = 0.0f;      // bias gradients: column sums of the A operands
+  const int d_in = n_view + E;
+  const int64_t n_tiles = (M + 31) / 32;
+
+  // staging registers for the next tile: 4 matrices x 4 float4 per thread, 8 x-values, <= 1 gz value.
+  // (Written inline with unconditional, address-clamped loads: conditional loads or lambdas here made
+  //  hipcc keep the staging arrays in scratch and wait for every load individually.)
+  float4 pg1[4], pg2[4], ph1[4], ph2[4];
+  float px[8], pgz;
+#define SHADE_WGRAD_PREFETCH(TILE)                                                                   \
+  {                                                                                                  \
+    const int64_t r0_ = (TILE) * 32;                                                                 \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                  \
+      const int idx = tid + 256 * i;                                                                 \
+      const int64_t row = r0_ + (idx >> 5);                                                          \
+      const int64_t off = (row < M ? row : M - 1) * WIDTH + 4 * (idx & 31);                          \
+      pg1[i] = *reinterpret_cast<const float4*>(G1 + off);                                           \
+      pg2[i] = *reinterpret_cast<const float4*>(G2 + off);                                           \
+      ph1[i] = *reinterpret_cast<const float4*>(H1 + off);                                           \
+      ph2[i] = *reinterpret_cast<const float4*>(H2 + off);                                           \
+    }                                                                                                \
+    {                                                                                                \
+      const int64_t row = r0_ + (tid >> 3);                                                          \
+      const int64_t rc = row < M ? row : M - 1;                                                      \
+      const float* fr = feat + rc * C + c_view0;                                                     \
+      const float* er = emb + ray_id[rc] * E - n_view;                                               \
+      _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                \
+        const int k = (tid & 7) + 8 * i;                                                             \
+        const int kc = k < d_in ? k : d_in - 1;                                                      \
+        const float v = (kc < n_view) ? fr[kc] : er[kc];                                             \
+        px[i] = (k < d_in) ? v : 0.0f;                                                               \
+      }                                                                                              \
+    }                                                                                                \
+    {                                                                                                \
+      const int64_t row = r0_ + ((tid & 127) >> 2);                                                  \
+      const int64_t rc = row < M ? row : M - 1;                                                      \
+      const int c = (tid & 3) < 3 ? (tid & 3) : 0;                                                   \
+      pgz = gz[rc * 3 + c];                                                                          \
+    }                                                                                                \
+  }
+
+  int64_t tile = blockIdx.x;
+  if (tile < n_tiles) SHADE_WGRAD_PREFETCH(tile);
+  for (; tile < n_tiles; tile += gridDim.x) {
+    {   // commit the staged tile to LDS; rows past M are zeroed here (they were loaded from a clamped row)
+      const int64_t r0 = tile * 32;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int idx = tid + 256 * i;
+        const int row = idx >> 5, c4 = 4 * (idx & 31);
+        const float m = (r0 + row < M) ? 1.0f : 0.0f;
+        *reinterpret_cast<float4*>(&L.g1[row][c4]) = make_float4(pg1[i].x * m, pg1[i].y * m, pg1[i].z * m, pg1[i].w * m);
+        *reinterpret_cast<float4*>(&L.g2[row][c4]) = make_float4(pg2[i].x * m, pg2[i].y * m, pg2[i].z * m, pg2[i].w * m);
+        *reinterpret_cast<float4*>(&L.h1[row][c4]) = ph1[i];
+        *reinterpret_cast<float4*>(&L.h2[row][c4]) = ph2[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) L.x[tid >> 3][(tid & 7) + 8 * i] = px[i];
+      if (tid < 128) L.gz[tid >> 2][tid & 3] = ((tid & 3) < 3 && r0 + (tid >> 2) < M) ? pgz : 0.0f;
+    }
+    __syncthreads();
+    const int64_t nxt = tile + gridDim.x;
+    SHADE_WGRAD_PREFETCH(nxt < n_tiles ? nxt : tile);      // overlaps with the MFMAs below (last one is redundant)
+#pragma unroll 4
+    for (int s = 0; s < 16; ++s) {
+      const int row = 2 * s + h;
+      const float a2 = L.g2[row][32 * w + j];
+      const float a1 = L.g1[row][32 * w + j];
+      const float a3 = (j < 3) ? L.gz[row][j] : 0.0f;
+      sb2 += a2; sb1 += a1; sb3 += a3;
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+        aW2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, L.h1[row][32 * t + j], aW2[t], 0, 0, 0);
+      aW1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, L.x[row][j], aW1[0], 0, 0, 0);
+      aW1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, L.x[row][32 + j], aW1[1], 0, 0, 0);
+      aW3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, L.h2[row][32 * w + j], aW3, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+#undef SHADE_WGRAD_PREFETCH
+  // D[row = (r&3) + 8*(r>>2) + 4*h][col = j]
+  float* p = part + (int64_t)blockIdx.x * (WIDTH * WIDTH + WIDTH * 64 + 32 * WIDTH + 3 * WIDTH);
+  float* pW2 = p;                          // [WIDTH out][WIDTH in]
+  float* pW1 = pW2 + WIDTH * WIDTH;        // [WIDTH out][64]
+  float* pW3 = pW1 + WIDTH * 64;           // [32 (c padded)][WIDTH]
+  float* pb = pW3 + 32 * WIDTH;            // [3][WIDTH]: db1, db2, db3 (first 3 entries)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+#pragma unroll
+    for (int t = 0; t < T; ++t) pW2[(32 * w + i) * WIDTH + 32 * t + j] = aW2[t][r];
+    pW1[(32 * w + i) * 64 + j] = aW1[0][r];
+    pW1[(32 * w + i) * 64 + 32 + j] = aW1[1][r];
+    pW3[i * WIDTH + 32 * w + j] = aW3[r];
+  }
+  // bias sums: lanes j and j+32 hold the even / odd rows of the same feature
+  sb1 += __shfl_xor(sb1, 32); sb2 += __shfl_xor(sb2, 32); sb3 += __shfl_xor(sb3, 32);
+  if (h == 0) {
+    pb[32 * w + j] = sb1;
+    pb[WIDTH + 32 * w + j] = sb2;
+    if (w == 0) pb[2 * WIDTH + j] = sb3;
+  }
+}
+
+extern "C" {
+
+int dvgo_shade_fwd(const float* feat, int C, const float* emb, int E, const int64_t* ray_id, int64_t M,
+                   const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
+                   const float* b3, int width, int d_in, int diffuse, float* rgb, float* H1, float* H2,
+                   void* stream) {
+  if (M < 0 || C <= 0 || E < 0) return DVGO_EINVAL;
+  if (M == 0) return 0;
+  if (!feat || !emb || !ray_id || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !rgb) return DVGO_EINVAL;
+  if ((H1 == nullptr) != (H2 == nullptr)) return DVGO_EINVAL;
+  const int c_view0 = diffuse ? 3 : 0;
+  const int n_view = C - c_view0;
+  if (n_view < 0 || d_in != n_view + E) return DVGO_EINVAL;
+  if (width != 128 || d_in > 40) return DVGO_ERANGE;     // shapes outside the instantiated set: caller falls back
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t n_tiles = (M + 31) / 32;
+  int blocks = (int)((n_tiles + SHADE_WAVES - 1) / SHADE_WAVES < 256 ? (n_tiles + SHADE_WAVES - 1) / SHADE_WAVES : 256);
+#define DVGO_SHADE(S1, DIFF)                                                                              \
+  shade_fwd_kernel<128, S1, DIFF><<<blocks, SHADE_THREADS, 0, s>>>(feat, C, c_view0, n_view, emb, E, ray_id, M, W1, b1, W2, \
+                                                          b2, W3, b3, d_in, rgb, H1, H2)
+  if (d_in <= 36) { if (diffuse) DVGO_SHADE(18, true); else DVGO_SHADE(18, false); }
+  else            { if (diffuse) DVGO_SHADE(20, true); else DVGO_SHADE(20, false); }
+#undef DVGO_SHADE
+  DVGO_LAUNCH_CHECK();
+  return 0;
+}
+
+int dvgo_shade_bwd(const float* g_rgb, const float* rgb, const float* H1, const float* H2, int64_t M,
+                   const float* W1, const float* W2, const float* W3, int width, int d_in, int C, int diffuse,
+                   float* g_feat, float* G1, float* G2, float* gz, void* stream) {
+  if (M < 0 || C <= 0) return DVGO_EINVAL;
+  if (M == 0) return 0;
+  if (!g_rgb || !rgb || !H1 || !H2 || !W1 || !W2 || !W3 || !g_feat || !G1 || !G2 || !gz) return DVGO_EINVAL;
+  const int c_view0 = diffuse ? 3 : 0;
+  const int n_view = C - c_view0;
+  if (width != 128 || n_view < 0 || n_view > 32 || d_in < n_view) return DVGO_ERANGE;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t n_tiles = (M + 31) / 32;
+  int blocks = (int)((n_tiles + SHADE_WAVES - 1) / SHADE_WAVES < 256 ? (n_tiles + SHADE_WAVES - 1) / SHADE_WAVES : 256);
+  if (diffuse)
+    shade_bwd_kernel<128, true><<<blocks, SHADE_THREADS, 0, s>>>(g_rgb, rgb, H1, H2, M, W1, W2, W3, d_in, C, c_view0,
+                                                                 n_view, g_feat, G1, G2, gz);
+  else
+    shade_bwd_kernel<128, false><<<blocks, SHADE_THREADS, 0, s>>>(g_rgb, rgb, H1, H2, M, W1, W2, W3, d_in, C, c_view0,
+                                                                  n_view, g_feat, G1, G2, gz);
+  DVGO_LAUNCH_CHECK();
+  return 0;
+}
+
+int dvgo_shade_wgrad(const float* G1, const float* G2, const float* gz, const float* H1, const float* H2,
+                     const float* feat, int C, const float* emb, int E, const int64_t* ray_id, int64_t M, int width,
+                     int diffuse, int n_parts, float* part, void* stream) {
+  if (M < 0 || n_parts <= 0 || C <= 0 || E < 0) return DVGO_EINVAL;
+  if (!G1 || !G2 || !gz || !H1 || !H2 || !feat || !emb || !ray_id || !part) return DVGO_EINVAL;
+  const int c_view0 = diffuse ? 3 : 0;
+  const int n_view = C - c_view0;
+  if (width != 128 || n_view < 0 || n_view + E > 64) return DVGO_ERANGE;
+  shade_wgrad_kernel<128><<<n_parts, 256, 0, (hipStream_t)stream>>>(G1, G2, gz, H1, H2, feat, C, c_view0, n_view, emb, E,
+                                                                    ray_id, M, part);
+  DVGO_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // extern "C"

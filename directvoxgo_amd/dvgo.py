@@ -24,6 +24,7 @@ import torch.nn.functional as F
 from . import render_utils as render_utils_hip
 from .fused import MarchConfig, composite, composite_depth, fused_march
 from .ops import Alphas2Weights, MaskCache, Raw2Alpha, grid_sample, segment_coo, total_variation_add_grad
+from .shade import shade
 
 
 def _as_f32(x):
@@ -97,6 +98,7 @@ class DirectVoxGO(nn.Module):
             raise NotImplementedError('fork-specific LIIF / posbase_pe / full-implicit variants are out of scope')
         self.verbose = verbose
         self.fused = bool(fused)
+        self.fused_shade = True          # fp32-MFMA colour head (csrc/shade.hip) when the rgbnet has the default shape
         self.channels_last = bool(channels_last)
         xyz_min, xyz_max = _as_f32(xyz_min), _as_f32(xyz_max)
         self.register_buffer('xyz_min', xyz_min.clone())
@@ -306,6 +308,10 @@ class DirectVoxGO(nn.Module):
             k0_diffuse = k0[:, :3]
         viewdirs_emb = (viewdirs.unsqueeze(-1) * self.viewfreq).flatten(-2)
         viewdirs_emb = torch.cat([viewdirs, viewdirs_emb.sin(), viewdirs_emb.cos()], -1)
+        if self.fused and self.fused_shade:
+            rgb = shade(self.rgbnet, k0, viewdirs_emb.flatten(0, -2), ray_id, diffuse=not self.rgbnet_direct)
+            if rgb is not None:
+                return rgb
         viewdirs_emb = viewdirs_emb.flatten(0, -2)[ray_id]
         rgb_logit = mlp_forward(self.rgbnet, torch.cat([k0_view, viewdirs_emb], -1))
         if self.rgbnet_direct:

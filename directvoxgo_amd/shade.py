@@ -1,0 +1,94 @@
+"""Fused colour head (rgbnet) -- host side of csrc/shade.hip (row N3 of SURVEY.md section 8f).
+
+`shade(...)` computes what /root/reference/lib/dvgo.py:516-541 computes with
+`viewdirs_emb[ray_id]`, `torch.cat`, three `nn.Linear`s, two ReLUs and a sigmoid, in one fp32-MFMA
+kernel.  It applies to the reference's default head, Sequential(Linear, ReLU, Sequential(Linear, ReLU),
+Linear) with width 128; other shapes return None and the caller keeps the torch modules.
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from ._lib import _i64, _int, ptr, stream_of
+
+N_PARTS = 768     # workgroups (= partial sums) of the weight-gradient kernel: three per CU
+
+
+def head_layers(rgbnet):
+    """(lin1, lin2, lin3) when the module tree is the 3-layer head the kernel implements, else None."""
+    if not isinstance(rgbnet, nn.Sequential) or len(rgbnet) != 4:
+        return None
+    a, r, mid, c = rgbnet
+    if not (isinstance(a, nn.Linear) and isinstance(r, nn.ReLU) and isinstance(c, nn.Linear)):
+        return None
+    if not (isinstance(mid, nn.Sequential) and len(mid) == 2 and isinstance(mid[0], nn.Linear) and isinstance(mid[1], nn.ReLU)):
+        return None
+    if a.out_features != 128 or mid[0].in_features != 128 or mid[0].out_features != 128 or c.out_features != 3:
+        return None
+    if a.in_features > 40:
+        return None
+    return a, mid[0], c
+
+
+class _Shade(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, emb, ray_id, W1, b1, W2, b2, W3, b3, diffuse):
+        M, C = feat.shape
+        E = emb.shape[1]
+        width, d_in = W1.shape
+        feat, emb = feat.contiguous(), emb.contiguous()
+        train = any(ctx.needs_input_grad)
+        rgb = torch.empty((M, 3), dtype=torch.float32, device=feat.device)
+        H1 = torch.empty((M, width), dtype=torch.float32, device=feat.device) if train else None
+        H2 = torch.empty((M, width), dtype=torch.float32, device=feat.device) if train else None
+        with torch.cuda.device_of(feat):
+            L.call('dvgo_shade_fwd', ptr(feat), _int(C), ptr(emb), _int(E), ptr(ray_id), _i64(M), ptr(W1.contiguous()),
+                   ptr(b1.contiguous()), ptr(W2.contiguous()), ptr(b2.contiguous()), ptr(W3.contiguous()),
+                   ptr(b3.contiguous()), _int(width), _int(d_in), _int(1 if diffuse else 0), ptr(rgb), ptr(H1), ptr(H2),
+                   stream_of(feat))
+        if train:
+            ctx.save_for_backward(feat, emb, ray_id, W1, W2, W3, rgb, H1, H2)
+            ctx.diffuse = diffuse
+        return rgb
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_rgb):
+        feat, emb, ray_id, W1, W2, W3, rgb, H1, H2 = ctx.saved_tensors
+        diffuse = ctx.diffuse
+        M, C = feat.shape
+        width, d_in = W1.shape
+        g_feat = torch.empty_like(feat)
+        G1 = torch.empty_like(H1)
+        G2 = torch.empty_like(H2)
+        gz = torch.empty_like(rgb)
+        psize = width * width + width * 64 + 32 * width + 3 * width
+        part = torch.empty((N_PARTS, psize), dtype=torch.float32, device=feat.device)
+        with torch.cuda.device_of(feat):
+            L.call('dvgo_shade_bwd', ptr(g_rgb.contiguous()), ptr(rgb), ptr(H1), ptr(H2), _i64(M), ptr(W1.contiguous()),
+                   ptr(W2.contiguous()), ptr(W3.contiguous()), _int(width), _int(d_in), _int(C), _int(1 if diffuse else 0),
+                   ptr(g_feat), ptr(G1), ptr(G2), ptr(gz), stream_of(feat))
+            L.call('dvgo_shade_wgrad', ptr(G1), ptr(G2), ptr(gz), ptr(H1), ptr(H2), ptr(feat), _int(C), ptr(emb),
+                   _int(emb.shape[1]), ptr(ray_id), _i64(M), _int(width), _int(1 if diffuse else 0), _int(N_PARTS),
+                   ptr(part), stream_of(feat))
+        tot = part.sum(0)
+        o = 0
+        gW2 = tot[o:o + width * width].view(width, width); o += width * width
+        gW1 = tot[o:o + width * 64].view(width, 64)[:, :d_in]; o += width * 64
+        gW3 = tot[o:o + 32 * width].view(32, width)[:3]; o += 32 * width
+        gb1, gb2, gb3 = tot[o:o + width], tot[o + width:o + 2 * width], tot[o + 2 * width:o + 2 * width + 3]
+        return (g_feat if ctx.needs_input_grad[0] else None, None, None, gW1.contiguous(), gb1, gW2, gb2,
+                gW3.contiguous(), gb3, None)
+
+
+def shade(rgbnet, feat, emb, ray_id, diffuse):
+    """rgb [M,3] = sigmoid(rgbnet(cat([feat[:,3:] if diffuse else feat, emb[ray_id]])) + (feat[:,:3] if diffuse)),
+    or None when the head is not the shape the kernel was built for."""
+    layers = head_layers(rgbnet)
+    if layers is None or not feat.is_cuda:
+        return None
+    l1, l2, l3 = layers
+    c0 = 3 if diffuse else 0
+    if l1.in_features != feat.shape[1] - c0 + emb.shape[1]:
+        return None
+    return _Shade.apply(feat, emb, ray_id, l1.weight, l1.bias, l2.weight, l2.bias, l3.weight, l3.bias, diffuse)

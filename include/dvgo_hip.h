@@ -253,6 +253,38 @@ int dvgo_march_density_bwd(const dvgo_rec2_t* rec2, const int32_t* n2, const int
                            int X, int Y, int Z, float* grad_density, void* stream);
 
 /* ---------------------------------------------------------------------------------
+ * "next" row N3: fused colour head (rgbnet) forward.  Replaces lib/dvgo.py:516-541 for the
+ * Sequential(Linear(d_in,width), ReLU, Linear(width,width), ReLU, Linear(width,3)) head:
+ *   x   = cat([feat[:, 3:] if diffuse else feat, emb[ray_id]])       d_in = C - (3 if diffuse) + E
+ *   rgb = sigmoid(MLP(x) + (feat[:, :3] if diffuse))
+ * feat [M,C], emb [N_rays,E] (view-direction embedding per ray), ray_id [M] int64.  Weights in
+ * nn.Linear layout ([out,in] row-major).  fp32 throughout (v_mfma_f32_32x32x2_f32).
+ * Training (both or neither): H1, H2 [M,width] = post-ReLU activations, row-major.
+ * Returns DVGO_ERANGE for shapes outside the built set (width == 128, d_in <= 40): fall back.
+ * --------------------------------------------------------------------------------- */
+int dvgo_shade_fwd(const float* feat, int C, const float* emb, int E, const int64_t* ray_id, int64_t M,
+                   const float* W1, const float* b1, const float* W2, const float* b2,
+                   const float* W3, const float* b3, int width, int d_in, int diffuse,
+                   float* rgb, float* H1, float* H2, void* stream);
+
+/* Data-gradient part of the colour-head backward.  Inputs: g_rgb, rgb [M,3]; the saved activations
+ * H1, H2 [M,width].  Outputs: gz [M,3] (= g_rgb * sigmoid'), G2 = relu'(H2) * (W3^T gz) and
+ * G1 = relu'(H1) * (W2^T G2) as [M,width] (operands of dvgo_shade_wgrad), and g_feat [M,C] fully written:
+ * channels [0,3) = gz when diffuse, channels [c0, C) = (W1^T G1)[:C-c0]. */
+int dvgo_shade_bwd(const float* g_rgb, const float* rgb, const float* H1, const float* H2, int64_t M,
+                   const float* W1, const float* W2, const float* W3, int width, int d_in, int C, int diffuse,
+                   float* g_feat, float* G1, float* G2, float* gz, void* stream);
+
+/* Weight-gradient part: dW2 = G2^T H1, dW1 = G1^T X (X = the layer-1 input, re-assembled from feat / emb /
+ * ray_id exactly as in dvgo_shade_fwd), dW3 = gz^T H2 and the three bias gradients (column sums); fp32 MFMA
+ * with both operands read row-major straight from memory.  Every one of the n_parts workgroups writes its
+ * partial sums to part[p] = { dW2 [width][width], dW1 [width][64], dW3 [32][width] (rows 0..2 valid),
+ * db1 [width], db2 [width], db3 [width] (first 3 valid) } floats; the caller sums over p. */
+int dvgo_shade_wgrad(const float* G1, const float* G2, const float* gz, const float* H1, const float* H2,
+                     const float* feat, int C, const float* emb, int E, const int64_t* ray_id, int64_t M,
+                     int width, int diffuse, int n_parts, float* part, void* stream);
+
+/* ---------------------------------------------------------------------------------
  * "next" rows N1/N2: optimizer and regulariser kernels.
  *   adam_upd_cuda.{adam_upd,masked_adam_upd,adam_upd_with_perlr}
  *     (lib/cuda/adam_upd.cpp:36-86, adam_upd_kernel.cu) -- mode 0/1/2, in place.

@@ -294,3 +294,36 @@ def test_total_variation(ops, oracle, dense):
         gt = cu(grad).contiguous(memory_format=fmt)
         ops.total_variation_add_grad(pt, gt, 0.3, 0.6, 1.2, dense)
         np.testing.assert_array_equal(gt.cpu().numpy(), exp)
+
+
+# ------------------------------------------------------------------ N3 fused colour head
+@pytest.mark.parametrize('M,diffuse', [(1, True), (31, True), (1000, False), (70001, True)])
+def test_shade_matches_torch_modules(M, diffuse):
+    """csrc/shade.hip (fp32 MFMA) vs the torch modules it replaces (lib/dvgo.py:516-541), values and grads."""
+    from directvoxgo_amd.dvgo import make_rgbnet
+    from directvoxgo_amd.shade import shade
+    torch.manual_seed(M)
+    C, E, N = 12, 27, 50
+    d_in = (C - 3 if diffuse else C) + E
+    net = make_rgbnet(d_in, 128, 3).cuda()
+    feat = torch.randn(M, C, device='cuda', requires_grad=True)
+    emb = torch.randn(N, E, device='cuda')
+    ray_id = torch.sort(torch.randint(N, (M,), device='cuda'))[0]
+    rgb = shade(net, feat, emb, ray_id, diffuse)
+    assert rgb is not None and rgb.shape == (M, 3)
+    x = torch.cat([feat[:, 3:] if diffuse else feat, emb[ray_id]], -1)
+    ref = torch.sigmoid(net(x) + (feat[:, :3] if diffuse else 0))
+    np.testing.assert_allclose(rgb.detach().cpu().numpy(), ref.detach().cpu().numpy(), rtol=1e-5, atol=2e-6)
+    go = torch.randn_like(ref)
+    gr = torch.autograd.grad(ref, [feat] + list(net.parameters()), go)
+    gs = torch.autograd.grad(rgb, [feat] + list(net.parameters()), go)
+    for a, b in zip(gs, gr):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-4, atol=2e-5 * max(1.0, float(b.abs().max())))
+
+
+def test_shade_falls_back_for_other_heads():
+    from directvoxgo_amd.dvgo import make_rgbnet
+    from directvoxgo_amd.shade import shade
+    net = make_rgbnet(36, 64, 3).cuda()
+    assert shade(net, torch.randn(5, 12, device='cuda'), torch.randn(2, 27, device='cuda'),
+                 torch.zeros(5, dtype=torch.int64, device='cuda'), True) is None
