@@ -218,7 +218,7 @@ def main():
     ap.add_argument('--workload', default='roofline', choices=['roofline', 'lego'])
     ap.add_argument('--no-secondary', action='store_true', help='skip the lego-like secondary measurement')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample-rays', type=int, default=512)
+    ap.add_argument('--cpu-sample-rays', type=int, default=4096)
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend for N > 1 ('nccl' = RCCL on ROCm)")
     args = ap.parse_args()
 
