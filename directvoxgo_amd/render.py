@@ -91,3 +91,65 @@ def render_viewpoints(model, render_poses, HW, Ks, ndc, render_kwargs, flip_x=Fa
     rgbs = np.stack([mine[i][0].cpu().numpy() for i in idx]) if idx else np.zeros((0,))
     depths = np.stack([mine[i][1].cpu().numpy() for i in idx]) if idx else np.zeros((0,))
     return rgbs, depths
+
+
+# ----------------------------------------------------------------------------------------------
+# Training-ray gathering (lib/ray_utils.py:88-183, 283-290)
+# ----------------------------------------------------------------------------------------------
+@torch.no_grad()
+def get_training_rays(rgb_tr, train_poses, HW, Ks, ndc, inverse_y, flip_x, flip_y):
+    """Per-image ray tensors [n_img,H,W,3] for same-sized images (lib/ray_utils.py:88-110)."""
+    assert len(np.unique(HW, axis=0)) == 1 and len(rgb_tr) == len(train_poses) == len(Ks) == len(HW)
+    H, W = int(HW[0][0]), int(HW[0][1])
+    dev = rgb_tr.device
+    per_view = [get_rays_of_a_view(H, W, Ks[0], torch.as_tensor(np.asarray(c2w), dtype=torch.float32, device=dev),
+                                   ndc, inverse_y, flip_x, flip_y) for c2w in train_poses]
+    rays_o, rays_d, viewdirs = (torch.stack([v[k] for v in per_view]) for k in range(3))
+    return rgb_tr, rays_o, rays_d, viewdirs, [1] * len(rgb_tr)
+
+
+@torch.no_grad()
+def get_training_rays_flatten(rgb_tr_ori, train_poses, HW, Ks, ndc, inverse_y, flip_x, flip_y):
+    """All pixels of all (possibly differently sized) images as flat [N,3] tensors (lib/ray_utils.py:113-142)."""
+    assert len(rgb_tr_ori) == len(train_poses) == len(Ks) == len(HW)
+    dev = rgb_tr_ori[0].device
+    rgb, ro, rd, vd, imsz = [], [], [], [], []
+    for c2w, img, (H, W), K in zip(train_poses, rgb_tr_ori, HW, Ks):
+        assert tuple(img.shape[:2]) == (int(H), int(W))
+        o, d, v = get_rays_of_a_view(int(H), int(W), K, torch.as_tensor(np.asarray(c2w), dtype=torch.float32, device=dev),
+                                     ndc, inverse_y, flip_x, flip_y)
+        rgb.append(img.flatten(0, 1)); ro.append(o.flatten(0, 1)); rd.append(d.flatten(0, 1)); vd.append(v.flatten(0, 1))
+        imsz.append(int(H) * int(W))
+    return torch.cat(rgb), torch.cat(ro), torch.cat(rd), torch.cat(vd), imsz
+
+
+@torch.no_grad()
+def get_training_rays_in_maskcache_sampling(rgb_tr_ori, train_poses, HW, Ks, ndc, inverse_y, flip_x, flip_y, model,
+                                            render_kwargs, rows_per_call=64):
+    """Only the rays that hit known-occupied space (lib/ray_utils.py:145-183): `model.hit_coarse_geo`
+    (sampler + mask lookup kernels) over 64 image rows at a time."""
+    assert len(rgb_tr_ori) == len(train_poses) == len(Ks) == len(HW)
+    dev = rgb_tr_ori[0].device
+    rgb, ro, rd, vd, imsz = [], [], [], [], []
+    n_all = 0
+    for c2w, img, (H, W), K in zip(train_poses, rgb_tr_ori, HW, Ks):
+        o, d, v = get_rays_of_a_view(int(H), int(W), K, torch.as_tensor(np.asarray(c2w), dtype=torch.float32, device=dev),
+                                     ndc, inverse_y, flip_x, flip_y)
+        hit = torch.cat([model.hit_coarse_geo(rays_o=o[i:i + rows_per_call], rays_d=d[i:i + rows_per_call], **render_kwargs)
+                         for i in range(0, int(H), rows_per_call)])
+        rgb.append(img[hit]); ro.append(o[hit]); rd.append(d[hit]); vd.append(v[hit])
+        imsz.append(int(hit.sum()))
+        n_all += int(H) * int(W)
+    return torch.cat(rgb), torch.cat(ro), torch.cat(rd), torch.cat(vd), imsz
+
+
+def batch_indices_generator(N, BS, seed=None):
+    """Endless stream of index batches from a NumPy permutation, reshuffled when exhausted
+    (lib/ray_utils.py:283-290)."""
+    rng = np.random if seed is None else np.random.RandomState(seed)
+    idx, top = torch.from_numpy(rng.permutation(N)), 0
+    while True:
+        if top + BS > N:
+            idx, top = torch.from_numpy(rng.permutation(N)), 0
+        yield idx[top:top + BS]
+        top += BS
