@@ -81,7 +81,8 @@ __device__ __forceinline__ void shade_load_weights(ShadeLds<WIDTH, S1>& L, const
 template <int WIDTH, int S1>
 __device__ __forceinline__ void shade_tile_forward(const ShadeLds<WIDTH, S1>& L, const float (&x)[S1], int lane,
                                                    f32x16 (&acc1)[WIDTH / 32], float (&z)[3],
-                                                   float* __restrict__ H2row /* H2 + row*WIDTH or nullptr */) {
+                                                   float* __restrict__ H2row /* H2 + row*WIDTH or nullptr */,
+                                                   unsigned long long& mask2 /* bit 16*t + r = (H2 feature f(t,r,h) > 0) */) {
   constexpr int T = WIDTH / 32;
   const int h = lane >> 5;
 #pragma unroll
@@ -94,6 +95,7 @@ __device__ __forceinline__ void shade_tile_forward(const ShadeLds<WIDTH, S1>& L,
     for (int r = 0; r < 16; ++r) acc1[t][r] = fmaxf(acc1[t][r], 0.0f);
   }
   float p[3] = {0.0f, 0.0f, 0.0f};
+  mask2 = 0ull;
 #pragma unroll 1      // keeps the scheduler from hoisting every tile's LDS reads (and spilling)
   for (int t2 = 0; t2 < T; ++t2) {
     f32x16 acc2;
@@ -108,6 +110,10 @@ __device__ __forceinline__ void shade_tile_forward(const ShadeLds<WIDTH, S1>& L,
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc2[r] = fmaxf(acc2[r], 0.0f);
     if (H2row != nullptr) {
+      unsigned int bits = 0u;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bits |= (acc2[r] > 0.0f ? 1u : 0u) << r;
+      mask2 |= (unsigned long long)bits << (16 * t2);
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         *reinterpret_cast<float4*>(H2row + 32 * t2 + 8 * q + 4 * h) =
@@ -149,7 +155,7 @@ shade_fwd_kernel(const float* __restrict__ feat, int C, int c_view0, int n_view,
                  const int64_t* __restrict__ ray_id, int64_t M, const float* __restrict__ W1,
                  const float* __restrict__ b1, const float* __restrict__ W2, const float* __restrict__ b2,
                  const float* __restrict__ W3, const float* __restrict__ b3, int D_in, float* __restrict__ rgb,
-                 float* __restrict__ H1, float* __restrict__ H2) {
+                 float* __restrict__ H1, float* __restrict__ H2, unsigned long long* __restrict__ masks) {
   constexpr int T = WIDTH / 32;
   __shared__ ShadeLds<WIDTH, S1> L;
   shade_load_weights<WIDTH, S1>(L, W1, b1, W2, b2, W3, b3, D_in);
@@ -167,7 +173,8 @@ shade_fwd_kernel(const float* __restrict__ feat, int C, int c_view0, int n_view,
     f32x16 acc1[T];
     float z[3];
     const bool keep = valid && (H1 != nullptr);
-    shade_tile_forward<WIDTH, S1>(L, x, lane, acc1, z, keep ? (H2 + row * WIDTH) : nullptr);
+    unsigned long long mask2;
+    shade_tile_forward<WIDTH, S1>(L, x, lane, acc1, z, keep ? (H2 + row * WIDTH) : nullptr, mask2);
     if (valid) {
       if (h == 0) {
 #pragma unroll
@@ -176,7 +183,15 @@ shade_fwd_kernel(const float* __restrict__ feat, int C, int c_view0, int n_view,
           rgb[row * 3 + c] = 1.0f / (1.0f + expf(-zz));
         }
       }
-      if (H1 != nullptr) {     // training: keep the post-ReLU activations for the backward pass
+      if (H1 != nullptr) {     // training: keep the post-ReLU activations (weight gradients) and their
+        unsigned long long mask1 = 0ull;   // sign bits (ReLU masks of the data-gradient kernel: 32 B / row)
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mask1 |= (unsigned long long)(acc1[t][r] > 0.0f ? 1u : 0u) << (16 * t + r);
+        }
+        masks[(row * 2 + 0) * 2 + h] = mask1;
+        masks[(row * 2 + 1) * 2 + h] = mask2;
 #pragma unroll
         for (int t = 0; t < T; ++t) {
 #pragma unroll
@@ -210,8 +225,8 @@ struct ShadeBwdLds {
 
 template <int WIDTH, bool DIFFUSE>
 __global__ void __launch_bounds__(SHADE_THREADS)
-shade_bwd_kernel(const float* __restrict__ g_rgb, const float* __restrict__ rgb, const float* __restrict__ H1,
-                 const float* __restrict__ H2, int64_t M, const float* __restrict__ W1, const float* __restrict__ W2,
+shade_bwd_kernel(const float* __restrict__ g_rgb, const float* __restrict__ rgb,
+                 const unsigned long long* __restrict__ masks, int64_t M, const float* __restrict__ W1, const float* __restrict__ W2,
                  const float* __restrict__ W3, int D_in, int C, int c_view0, int n_view,
                  float* __restrict__ g_feat, float* __restrict__ G1, float* __restrict__ G2, float* __restrict__ gz_out) {
   constexpr int T = WIDTH / 32;
@@ -254,6 +269,9 @@ shade_bwd_kernel(const float* __restrict__ g_rgb, const float* __restrict__ rgb,
         if (DIFFUSE) g_feat[row * C + c] = gz[c];
       }
     }
+    // ReLU sign bits of this lane's 64 features per layer (bit 16*t + r <-> feature f(t,r,h))
+    const unsigned long long m1 = masks[(rowc * 2 + 0) * 2 + h];
+    const unsigned long long m2 = masks[(rowc * 2 + 1) * 2 + h];
     // G2 in accumulator layout (all T tiles stay live: they are the B operands below)
     f32x16 g2[T];
 #pragma unroll
@@ -261,15 +279,13 @@ shade_bwd_kernel(const float* __restrict__ g_rgb, const float* __restrict__ rgb,
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int f = 32 * t2 + 8 * q + 4 * h;
-        const float4 hv = *reinterpret_cast<const float4*>(H2 + rowc * WIDTH + f);
-        const float hh[4] = {hv.x, hv.y, hv.z, hv.w};
         float o[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * q + e;
           const float v = fmaf(L.w3p[2][h][t2 * 16 + r], gz[2],
                                fmaf(L.w3p[1][h][t2 * 16 + r], gz[1], L.w3p[0][h][t2 * 16 + r] * gz[0]));
-          o[e] = (hh[e] > 0.0f) ? v : 0.0f;          // gz == 0 on rows past M, so o == 0 there
+          o[e] = ((m2 >> (16 * t2 + r)) & 1ull) ? v : 0.0f;   // gz == 0 on rows past M, so o == 0 there
           g2[t2][r] = o[e];
         }
         if (valid) *reinterpret_cast<float4*>(G2 + row * WIDTH + f) = make_float4(o[0], o[1], o[2], o[3]);
@@ -292,11 +308,11 @@ shade_bwd_kernel(const float* __restrict__ g_rgb, const float* __restrict__ rgb,
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int f = 32 * tin + 8 * q + 4 * h;
-        const float4 hv = *reinterpret_cast<const float4*>(H1 + rowc * WIDTH + f);
-        acc[4 * q + 0] = (hv.x > 0.0f) ? acc[4 * q + 0] : 0.0f;
-        acc[4 * q + 1] = (hv.y > 0.0f) ? acc[4 * q + 1] : 0.0f;
-        acc[4 * q + 2] = (hv.z > 0.0f) ? acc[4 * q + 2] : 0.0f;
-        acc[4 * q + 3] = (hv.w > 0.0f) ? acc[4 * q + 3] : 0.0f;
+        const unsigned int mb = (unsigned int)(m1 >> (16 * tin + 4 * q)) & 15u;
+        acc[4 * q + 0] = (mb & 1u) ? acc[4 * q + 0] : 0.0f;
+        acc[4 * q + 1] = (mb & 2u) ? acc[4 * q + 1] : 0.0f;
+        acc[4 * q + 2] = (mb & 4u) ? acc[4 * q + 2] : 0.0f;
+        acc[4 * q + 3] = (mb & 8u) ? acc[4 * q + 3] : 0.0f;
         if (valid)
           *reinterpret_cast<float4*>(G1 + row * WIDTH + f) =
               make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
@@ -465,11 +481,11 @@ extern "C" {
 int dvgo_shade_fwd(const float* feat, int C, const float* emb, int E, const int64_t* ray_id, int64_t M,
                    const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
                    const float* b3, int width, int d_in, int diffuse, float* rgb, float* H1, float* H2,
-                   void* stream) {
+                   uint64_t* masks, void* stream) {
   if (M < 0 || C <= 0 || E < 0) return DVGO_EINVAL;
   if (M == 0) return 0;
   if (!feat || !emb || !ray_id || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !rgb) return DVGO_EINVAL;
-  if ((H1 == nullptr) != (H2 == nullptr)) return DVGO_EINVAL;
+  if ((H1 == nullptr) != (H2 == nullptr) || (H1 == nullptr) != (masks == nullptr)) return DVGO_EINVAL;
   const int c_view0 = diffuse ? 3 : 0;
   const int n_view = C - c_view0;
   if (n_view < 0 || d_in != n_view + E) return DVGO_EINVAL;
@@ -479,7 +495,7 @@ int dvgo_shade_fwd(const float* feat, int C, const float* emb, int E, const int6
   int blocks = (int)((n_tiles + SHADE_WAVES - 1) / SHADE_WAVES < 256 ? (n_tiles + SHADE_WAVES - 1) / SHADE_WAVES : 256);
 #define DVGO_SHADE(S1, DIFF)                                                                              \
   shade_fwd_kernel<128, S1, DIFF><<<blocks, SHADE_THREADS, 0, s>>>(feat, C, c_view0, n_view, emb, E, ray_id, M, W1, b1, W2, \
-                                                          b2, W3, b3, d_in, rgb, H1, H2)
+                                                          b2, W3, b3, d_in, rgb, H1, H2, (unsigned long long*)masks)
   if (d_in <= 36) { if (diffuse) DVGO_SHADE(18, true); else DVGO_SHADE(18, false); }
   else            { if (diffuse) DVGO_SHADE(20, true); else DVGO_SHADE(20, false); }
 #undef DVGO_SHADE
@@ -487,12 +503,12 @@ int dvgo_shade_fwd(const float* feat, int C, const float* emb, int E, const int6
   return 0;
 }
 
-int dvgo_shade_bwd(const float* g_rgb, const float* rgb, const float* H1, const float* H2, int64_t M,
+int dvgo_shade_bwd(const float* g_rgb, const float* rgb, const uint64_t* masks, int64_t M,
                    const float* W1, const float* W2, const float* W3, int width, int d_in, int C, int diffuse,
                    float* g_feat, float* G1, float* G2, float* gz, void* stream) {
   if (M < 0 || C <= 0) return DVGO_EINVAL;
   if (M == 0) return 0;
-  if (!g_rgb || !rgb || !H1 || !H2 || !W1 || !W2 || !W3 || !g_feat || !G1 || !G2 || !gz) return DVGO_EINVAL;
+  if (!g_rgb || !rgb || !masks || !W1 || !W2 || !W3 || !g_feat || !G1 || !G2 || !gz) return DVGO_EINVAL;
   const int c_view0 = diffuse ? 3 : 0;
   const int n_view = C - c_view0;
   if (width != 128 || n_view < 0 || n_view > 32 || d_in < n_view) return DVGO_ERANGE;
@@ -500,10 +516,10 @@ int dvgo_shade_bwd(const float* g_rgb, const float* rgb, const float* H1, const 
   const int64_t n_tiles = (M + 31) / 32;
   int blocks = (int)((n_tiles + SHADE_WAVES - 1) / SHADE_WAVES < 256 ? (n_tiles + SHADE_WAVES - 1) / SHADE_WAVES : 256);
   if (diffuse)
-    shade_bwd_kernel<128, true><<<blocks, SHADE_THREADS, 0, s>>>(g_rgb, rgb, H1, H2, M, W1, W2, W3, d_in, C, c_view0,
+    shade_bwd_kernel<128, true><<<blocks, SHADE_THREADS, 0, s>>>(g_rgb, rgb, (const unsigned long long*)masks, M, W1, W2, W3, d_in, C, c_view0,
                                                                  n_view, g_feat, G1, G2, gz);
   else
-    shade_bwd_kernel<128, false><<<blocks, SHADE_THREADS, 0, s>>>(g_rgb, rgb, H1, H2, M, W1, W2, W3, d_in, C, c_view0,
+    shade_bwd_kernel<128, false><<<blocks, SHADE_THREADS, 0, s>>>(g_rgb, rgb, (const unsigned long long*)masks, M, W1, W2, W3, d_in, C, c_view0,
                                                                   n_view, g_feat, G1, G2, gz);
   DVGO_LAUNCH_CHECK();
   return 0;

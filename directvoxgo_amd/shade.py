@@ -11,7 +11,7 @@ import torch.nn as nn
 from . import _lib as L
 from ._lib import _i64, _int, ptr, stream_of
 
-N_PARTS = 768     # workgroups (= partial sums) of the weight-gradient kernel: three per CU
+N_PARTS = 512     # workgroups (= partial sums) of the weight-gradient kernel: two resident per CU
 
 
 def head_layers(rgbnet):
@@ -41,20 +41,21 @@ class _Shade(torch.autograd.Function):
         rgb = torch.empty((M, 3), dtype=torch.float32, device=feat.device)
         H1 = torch.empty((M, width), dtype=torch.float32, device=feat.device) if train else None
         H2 = torch.empty((M, width), dtype=torch.float32, device=feat.device) if train else None
+        masks = torch.empty((M, 4), dtype=torch.int64, device=feat.device) if train else None
         with torch.cuda.device_of(feat):
             L.call('dvgo_shade_fwd', ptr(feat), _int(C), ptr(emb), _int(E), ptr(ray_id), _i64(M), ptr(W1.contiguous()),
                    ptr(b1.contiguous()), ptr(W2.contiguous()), ptr(b2.contiguous()), ptr(W3.contiguous()),
                    ptr(b3.contiguous()), _int(width), _int(d_in), _int(1 if diffuse else 0), ptr(rgb), ptr(H1), ptr(H2),
-                   stream_of(feat))
+                   ptr(masks), stream_of(feat))
         if train:
-            ctx.save_for_backward(feat, emb, ray_id, W1, W2, W3, rgb, H1, H2)
+            ctx.save_for_backward(feat, emb, ray_id, W1, W2, W3, rgb, H1, H2, masks)
             ctx.diffuse = diffuse
         return rgb
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_rgb):
-        feat, emb, ray_id, W1, W2, W3, rgb, H1, H2 = ctx.saved_tensors
+        feat, emb, ray_id, W1, W2, W3, rgb, H1, H2, masks = ctx.saved_tensors
         diffuse = ctx.diffuse
         M, C = feat.shape
         width, d_in = W1.shape
@@ -65,7 +66,7 @@ class _Shade(torch.autograd.Function):
         psize = width * width + width * 64 + 32 * width + 3 * width
         part = torch.empty((N_PARTS, psize), dtype=torch.float32, device=feat.device)
         with torch.cuda.device_of(feat):
-            L.call('dvgo_shade_bwd', ptr(g_rgb.contiguous()), ptr(rgb), ptr(H1), ptr(H2), _i64(M), ptr(W1.contiguous()),
+            L.call('dvgo_shade_bwd', ptr(g_rgb.contiguous()), ptr(rgb), ptr(masks), _i64(M), ptr(W1.contiguous()),
                    ptr(W2.contiguous()), ptr(W3.contiguous()), _int(width), _int(d_in), _int(C), _int(1 if diffuse else 0),
                    ptr(g_feat), ptr(G1), ptr(G2), ptr(gz), stream_of(feat))
             L.call('dvgo_shade_wgrad', ptr(G1), ptr(G2), ptr(gz), ptr(H1), ptr(H2), ptr(feat), _int(C), ptr(emb),

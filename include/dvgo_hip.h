@@ -259,19 +259,21 @@ int dvgo_march_density_bwd(const dvgo_rec2_t* rec2, const int32_t* n2, const int
  *   rgb = sigmoid(MLP(x) + (feat[:, :3] if diffuse))
  * feat [M,C], emb [N_rays,E] (view-direction embedding per ray), ray_id [M] int64.  Weights in
  * nn.Linear layout ([out,in] row-major).  fp32 throughout (v_mfma_f32_32x32x2_f32).
- * Training (both or neither): H1, H2 [M,width] = post-ReLU activations, row-major.
+ * Training (all or none): H1, H2 [M,width] = post-ReLU activations, row-major (operands of the weight
+ * gradients), and masks [M][2 layers][2 lane halves] uint64 = their sign bits in accumulator order (the ReLU
+ * masks of dvgo_shade_bwd: 32 B per sample instead of re-reading 1 KB of activations).
  * Returns DVGO_ERANGE for shapes outside the built set (width == 128, d_in <= 40): fall back.
  * --------------------------------------------------------------------------------- */
 int dvgo_shade_fwd(const float* feat, int C, const float* emb, int E, const int64_t* ray_id, int64_t M,
                    const float* W1, const float* b1, const float* W2, const float* b2,
                    const float* W3, const float* b3, int width, int d_in, int diffuse,
-                   float* rgb, float* H1, float* H2, void* stream);
+                   float* rgb, float* H1, float* H2, uint64_t* masks, void* stream);
 
 /* Data-gradient part of the colour-head backward.  Inputs: g_rgb, rgb [M,3]; the saved activations
- * H1, H2 [M,width].  Outputs: gz [M,3] (= g_rgb * sigmoid'), G2 = relu'(H2) * (W3^T gz) and
+ * sign-bit masks written by dvgo_shade_fwd.  Outputs: gz [M,3] (= g_rgb * sigmoid'), G2 = relu'(H2) * (W3^T gz) and
  * G1 = relu'(H1) * (W2^T G2) as [M,width] (operands of dvgo_shade_wgrad), and g_feat [M,C] fully written:
  * channels [0,3) = gz when diffuse, channels [c0, C) = (W1^T G1)[:C-c0]. */
-int dvgo_shade_bwd(const float* g_rgb, const float* rgb, const float* H1, const float* H2, int64_t M,
+int dvgo_shade_bwd(const float* g_rgb, const float* rgb, const uint64_t* masks, int64_t M,
                    const float* W1, const float* W2, const float* W3, int width, int d_in, int C, int diffuse,
                    float* g_feat, float* G1, float* G2, float* gz, void* stream);
 
