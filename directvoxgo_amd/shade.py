@@ -11,7 +11,7 @@ import torch.nn as nn
 from . import _lib as L
 from ._lib import _i64, _int, ptr, stream_of
 
-N_PARTS = 512     # workgroups (= partial sums) of the weight-gradient kernel: two resident per CU
+N_PARTS = 512     # max workgroups (= partial sums) of the weight-gradient kernel: two resident per CU
 
 
 def head_layers(rgbnet):
@@ -64,13 +64,14 @@ class _Shade(torch.autograd.Function):
         G2 = torch.empty_like(H2)
         gz = torch.empty_like(rgb)
         psize = width * width + width * 64 + 32 * width + 3 * width
-        part = torch.empty((N_PARTS, psize), dtype=torch.float32, device=feat.device)
+        n_parts = max(1, min(N_PARTS, (M + 511) // 512))      # >= 16 row tiles per workgroup on small batches
+        part = torch.empty((n_parts, psize), dtype=torch.float32, device=feat.device)
         with torch.cuda.device_of(feat):
             L.call('dvgo_shade_bwd', ptr(g_rgb.contiguous()), ptr(rgb), ptr(masks), _i64(M), ptr(W1.contiguous()),
                    ptr(W2.contiguous()), ptr(W3.contiguous()), _int(width), _int(d_in), _int(C), _int(1 if diffuse else 0),
                    ptr(g_feat), ptr(G1), ptr(G2), ptr(gz), stream_of(feat))
             L.call('dvgo_shade_wgrad', ptr(G1), ptr(G2), ptr(gz), ptr(H1), ptr(H2), ptr(feat), _int(C), ptr(emb),
-                   _int(emb.shape[1]), ptr(ray_id), _i64(M), _int(width), _int(1 if diffuse else 0), _int(N_PARTS),
+                   _int(emb.shape[1]), ptr(ray_id), _i64(M), _int(width), _int(1 if diffuse else 0), _int(n_parts),
                    ptr(part), stream_of(feat))
         tot = part.sum(0)
         o = 0

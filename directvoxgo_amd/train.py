@@ -20,6 +20,18 @@ import torch.nn as nn
 
 from .masked_adam import MaskedAdam
 
+def flat_view(t):
+    """1-D view of a dense tensor's memory (no copy): collectives want plain contiguous buffers, and the
+    feature grid / its gradient are stored channels-last."""
+    if t.is_contiguous():
+        return t.view(-1)
+    if t.dim() == 5 and t.is_contiguous(memory_format=torch.channels_last_3d):
+        v = t.permute(0, 2, 3, 4, 1).reshape(-1)
+        assert v.data_ptr() == t.data_ptr()
+        return v
+    return None
+
+
 COARSE_TRAIN = dict(
     N_iters=5000, N_rand=8192, lrate_density=1e-1, lrate_k0=1e-1, lrate_rgbnet=1e-3, lrate_decay=20,
     pervoxel_lr=True, weight_main=1.0, weight_entropy_last=0.01, weight_rgbper=0.1,
@@ -87,7 +99,13 @@ class TrainStep:
             return
         for p in (self.model.density, self.model.k0):
             if p.grad is not None:
-                dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.pg)
+                flat = flat_view(p.grad)
+                if flat is not None:                  # in place on the gradient's own memory
+                    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg)
+                else:                                 # exotic strides: staged through a contiguous copy
+                    tmp = p.grad.contiguous()
+                    dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=self.pg)
+                    p.grad.copy_(tmp)
         small = [p for p in self._small if p.grad is not None]
         if small:
             flat = torch.cat([p.grad.reshape(-1) for p in small])

@@ -26,7 +26,7 @@ class ToyModel(nn.Module):
         super().__init__()
         g = torch.Generator().manual_seed(5)
         self.density = nn.Parameter(torch.randn(1, 1, 5, 5, 5, generator=g))
-        self.k0 = nn.Parameter(torch.randn(1, 6, 5, 5, 5, generator=g) * 0.3)
+        self.k0 = nn.Parameter((torch.randn(1, 6, 5, 5, 5, generator=g) * 0.3).contiguous(memory_format=torch.channels_last_3d))
         self.rgbnet = nn.Sequential(nn.Linear(6, 8), nn.ReLU(), nn.Linear(8, 3))
         for p in self.rgbnet.parameters():
             p.data = torch.randn(p.shape, generator=g) * 0.3
@@ -108,6 +108,17 @@ def test_two_ranks_equal_one_process():
     assert torch.allclose(torch.from_numpy(losses), ref_losses, rtol=1e-5, atol=1e-7)
     for k, v in ref_model.state_dict().items():
         assert torch.allclose(torch.from_numpy(sd[k]), v, rtol=1e-5, atol=1e-6), k
+
+
+def test_flat_view_of_channels_last_grid_is_a_view():
+    from directvoxgo_amd.train import flat_view
+    g = torch.randn(1, 12, 5, 6, 7).contiguous(memory_format=torch.channels_last_3d)
+    v = flat_view(g)
+    assert v is not None and v.is_contiguous() and v.data_ptr() == g.data_ptr() and v.numel() == g.numel()
+    v.mul_(2)                                           # writes through to the grid
+    assert torch.equal(g.permute(0, 2, 3, 4, 1).reshape(-1), v)
+    assert flat_view(torch.randn(1, 1, 4, 4, 4)).numel() == 64
+    assert flat_view(torch.randn(4, 6)[:, ::2]) is None
 
 
 def test_render_loss_equals_reference_formula_on_one_rank():
