@@ -24,7 +24,7 @@ import torch.nn.functional as F
 from . import render_utils as render_utils_hip
 from .fused import MarchConfig, composite, composite_depth, fused_march
 from .ops import Alphas2Weights, MaskCache, Raw2Alpha, grid_sample, segment_coo, total_variation_add_grad
-from .shade import shade
+from .shade import shade, viewdir_embed
 
 
 def _as_f32(x):
@@ -306,12 +306,12 @@ class DirectVoxGO(nn.Module):
         else:
             k0_view = k0[:, 3:]
             k0_diffuse = k0[:, :3]
-        viewdirs_emb = (viewdirs.unsqueeze(-1) * self.viewfreq).flatten(-2)
-        viewdirs_emb = torch.cat([viewdirs, viewdirs_emb.sin(), viewdirs_emb.cos()], -1)
-        if self.fused and self.fused_shade:
-            rgb = shade(self.rgbnet, k0, viewdirs_emb.flatten(0, -2), ray_id, diffuse=not self.rgbnet_direct)
+        if self.fused and self.fused_shade and viewdirs.is_cuda and viewdirs.dim() == 2:
+            rgb = shade(self.rgbnet, k0, viewdir_embed(viewdirs, self.viewfreq), ray_id, diffuse=not self.rgbnet_direct)
             if rgb is not None:
                 return rgb
+        viewdirs_emb = (viewdirs.unsqueeze(-1) * self.viewfreq).flatten(-2)
+        viewdirs_emb = torch.cat([viewdirs, viewdirs_emb.sin(), viewdirs_emb.cos()], -1)
         viewdirs_emb = viewdirs_emb.flatten(0, -2)[ray_id]
         rgb_logit = mlp_forward(self.rgbnet, torch.cat([k0_view, viewdirs_emb], -1))
         if self.rgbnet_direct:

@@ -40,48 +40,79 @@ def adam_upd(param, grad, exp_avg, exp_avg_sq, step, beta1, beta2, lr, eps, mode
                stream_of(param))
 
 
+def adam_upd_multi(items, step, beta1, beta2, lr, eps):
+    """Plain Adam over up to 16 small (param, state) pairs in one launch (csrc/loss.hip)."""
+    import ctypes
+    n = len(items)
+    PT = ctypes.c_void_p * n
+    ps = PT(*[p.data_ptr() for p, _ in items])
+    gs = PT(*[p.grad.data_ptr() for p, _ in items])
+    ms = PT(*[st['exp_avg'].data_ptr() for _, st in items])
+    vs = PT(*[st['exp_avg_sq'].data_ptr() for _, st in items])
+    ne = (ctypes.c_int64 * n)(*[p.numel() for p, _ in items])
+    p0 = items[0][0]
+    with torch.cuda.device_of(p0):
+        L.call('dvgo_adam_upd_multi', ps, gs, ms, vs, ne, _int(n), _flt(adam_step_size(lr, beta1, beta2, step)), _flt(beta1),
+               _flt(beta2), _flt(eps), stream_of(p0))
+
+
 class MaskedAdam(torch.optim.Optimizer):
+    """Drop-in for lib/masked_adam.py:17-71 (same constructor, `set_pervoxel_lr`, param-group key
+    `skip_zero_grad`, state keys `step` / `exp_avg` / `exp_avg_sq`)."""
+
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.99), eps=1e-8):
-        if not 0.0 <= lr:
-            raise ValueError('Invalid learning rate: {}'.format(lr))
-        if not 0.0 <= eps:
-            raise ValueError('Invalid epsilon value: {}'.format(eps))
-        if not 0.0 <= betas[0] < 1.0 or not 0.0 <= betas[1] < 1.0:
-            raise ValueError('Invalid beta parameters: {}'.format(betas))
+        for name, val, ok in (('learning rate', lr, lr >= 0.0), ('epsilon value', eps, eps >= 0.0),
+                              ('beta parameter at index 0', betas[0], 0.0 <= betas[0] < 1.0),
+                              ('beta parameter at index 1', betas[1], 0.0 <= betas[1] < 1.0)):
+            if not ok:
+                raise ValueError(f'Invalid {name}: {val}')
         self.per_lr = None
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        super().__init__(params, {'lr': lr, 'betas': betas, 'eps': eps})
 
     def set_pervoxel_lr(self, count):
-        assert self.param_groups[0]['params'][0].shape == count.shape
+        """Per-voxel learning-rate multiplier = view count / max view count (run.py:311-320)."""
+        first = self.param_groups[0]['params'][0]
+        assert first.shape == count.shape
         self.per_lr = count.float() / count.max()
+
+    def _state_of(self, p):
+        st = self.state[p]
+        if not st:
+            st.update(step=0,
+                      exp_avg=torch.zeros_like(p, memory_format=torch.preserve_format),
+                      exp_avg_sq=torch.zeros_like(p, memory_format=torch.preserve_format))
+        return st
+
+    @staticmethod
+    def _like(p, t):
+        """`t` in the memory layout of `p` (the update kernels are element-wise over raw memory)."""
+        if t.stride() == p.stride():
+            return t
+        return torch.empty_like(p, memory_format=torch.preserve_format).copy_(t)
 
     @torch.no_grad()
     def step(self):
         for group in self.param_groups:
-            lr, (beta1, beta2), eps = group['lr'], group['betas'], group['eps']
-            skip_zero_grad = group.get('skip_zero_grad', False)
-            for param in group['params']:
-                if param.grad is None:
+            b1, b2 = group['betas']
+            masked = bool(group.get('skip_zero_grad', False))
+            small = []                                                   # plain-Adam tensors batched into one launch
+            for p in group['params']:
+                if p.grad is None:
                     continue
-                state = self.state[param]
-                if len(state) == 0:
-                    state['step'] = 0
-                    state['exp_avg'] = torch.zeros_like(param, memory_format=torch.preserve_format)
-                    state['exp_avg_sq'] = torch.zeros_like(param, memory_format=torch.preserve_format)
-                state['step'] += 1
-                grad = param.grad
-                if grad.stride() != param.stride():
-                    grad = torch.empty_like(param, memory_format=torch.preserve_format).copy_(grad)
-                if self.per_lr is not None and param.shape == self.per_lr.shape:
-                    per_lr = self.per_lr
-                    if per_lr.stride() != param.stride():
-                        per_lr = torch.empty_like(param, memory_format=torch.preserve_format).copy_(per_lr)
-                        self.per_lr = per_lr
-                    adam_upd(param, grad, state['exp_avg'], state['exp_avg_sq'], state['step'], beta1, beta2, lr,
-                             eps, mode=2, perlr=per_lr)
-                elif skip_zero_grad:
-                    adam_upd(param, grad, state['exp_avg'], state['exp_avg_sq'], state['step'], beta1, beta2, lr,
-                             eps, mode=1)
-                else:
-                    adam_upd(param, grad, state['exp_avg'], state['exp_avg_sq'], state['step'], beta1, beta2, lr,
-                             eps, mode=0)
+                st = self._state_of(p)
+                st['step'] += 1
+                use_perlr = self.per_lr is not None and p.shape == self.per_lr.shape
+                if use_perlr:
+                    self.per_lr = self._like(p, self.per_lr)
+                mode = 2 if use_perlr else (1 if masked else 0)           # dispatch order of :60-71
+                if mode == 0 and p.numel() <= 262144 and p.is_contiguous() and p.grad.is_contiguous() and p.is_cuda:
+                    small.append((p, st))
+                    continue
+                adam_upd(p, self._like(p, p.grad), st['exp_avg'], st['exp_avg_sq'], st['step'], b1, b2, group['lr'],
+                         group['eps'], mode=mode, perlr=self.per_lr if use_perlr else None)
+            by_step = {}
+            for p, st in small:
+                by_step.setdefault(st['step'], []).append((p, st))
+            for stp, items in by_step.items():
+                for i in range(0, len(items), 16):
+                    adam_upd_multi(items[i:i + 16], stp, b1, b2, group['lr'], group['eps'])

@@ -14,6 +14,18 @@ from ._lib import _i64, _int, ptr, stream_of
 N_PARTS = 512     # max workgroups (= partial sums) of the weight-gradient kernel: two resident per CU
 
 
+@torch.no_grad()
+def viewdir_embed(viewdirs, viewfreq):
+    """cat([v, sin(v (x) freq), cos(v (x) freq)]) of lib/dvgo.py:524-525 in one launch -> [N, 3 + 6F]."""
+    from ._lib import _flt  # noqa: F401
+    N, F = viewdirs.shape[0], viewfreq.shape[0]
+    emb = torch.empty((N, 3 + 6 * F), dtype=torch.float32, device=viewdirs.device)
+    with torch.cuda.device_of(viewdirs):
+        L.call('dvgo_viewdir_embed', ptr(viewdirs.contiguous()), ptr(viewfreq), _int(F), _i64(N), ptr(emb),
+               stream_of(viewdirs))
+    return emb
+
+
 def head_layers(rgbnet):
     """(lin1, lin2, lin3) when the module tree is the 3-layer head the kernel implements, else None."""
     if not isinstance(rgbnet, nn.Sequential) or len(rgbnet) != 4:

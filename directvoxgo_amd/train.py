@@ -79,11 +79,50 @@ def render_loss(render_result, target, n_rays_global, cfg_train):
     return loss
 
 
+class _FusedLoss(torch.autograd.Function):
+    """render_loss in one pass (csrc/loss.hip): the value and d/d{rgb_marched, alphainv_last, raw_rgb}."""
+
+    @staticmethod
+    def forward(ctx, rgb_marched, alphainv_last, raw_rgb, weights, ray_id, target, n_global, w_main, w_ent, w_per):
+        from . import _lib as L
+        from ._lib import _flt, _i64, ptr, stream_of
+        N, M = rgb_marched.shape[0], raw_rgb.shape[0]
+        dev = rgb_marched.device
+        rgb_marched, alphainv_last, raw_rgb = rgb_marched.contiguous(), alphainv_last.contiguous(), raw_rgb.contiguous()
+        g_marched = torch.empty_like(rgb_marched)
+        g_last = torch.empty_like(alphainv_last)
+        g_raw = torch.empty_like(raw_rgb) if w_per > 0 else None
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        with torch.cuda.device_of(rgb_marched):
+            L.call('dvgo_loss_fwd_bwd', ptr(rgb_marched), ptr(alphainv_last), ptr(target.contiguous()), _i64(N), ptr(raw_rgb),
+                   ptr(weights.contiguous()), ptr(ray_id), _i64(M), _i64(int(n_global)), _flt(w_main), _flt(w_ent),
+                   _flt(w_per), ptr(g_marched), ptr(g_last), ptr(g_raw), ptr(loss), stream_of(rgb_marched))
+        ctx.save_for_backward(g_marched, g_last, g_raw if g_raw is not None else g_last)
+        ctx.has_raw = g_raw is not None
+        return loss
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, go):
+        g_marched, g_last, g_raw = ctx.saved_tensors
+        return (g_marched * go, g_last * go, (g_raw * go) if ctx.has_raw else None, None, None, None, None, None, None,
+                None)
+
+
+def fused_render_loss(render_result, target, n_rays_global, cfg_train):
+    """Same value and gradients as `render_loss`, one kernel pair instead of ~40 framework launches."""
+    return _FusedLoss.apply(render_result['rgb_marched'], render_result['alphainv_last'], render_result['raw_rgb'],
+                            render_result['weights'].detach(), render_result['ray_id'], target, n_rays_global,
+                            float(cfg_train['weight_main']), float(cfg_train['weight_entropy_last']),
+                            float(cfg_train['weight_rgbper']))
+
+
 class TrainStep:
     """One optimisation step on one batch of rays; ``world_size > 1`` shards the batch by rank."""
 
-    def __init__(self, model, cfg_train, render_kwargs, optimizer=None, process_group=None):
+    def __init__(self, model, cfg_train, render_kwargs, optimizer=None, process_group=None, fused_loss=True):
         self.model = model
+        self.fused_loss = fused_loss
         self.cfg = cfg_train
         self.render_kwargs = render_kwargs
         self.optimizer = optimizer or create_optimizer_or_freeze_model(model, cfg_train, global_step=0)
@@ -122,7 +161,8 @@ class TrainStep:
         n_global = rays_o.shape[0] * self.world
         res = model(rays_o, rays_d, viewdirs, global_step=global_step, **self.render_kwargs)
         self.optimizer.zero_grad(set_to_none=True)
-        loss = render_loss(res, target, n_global, cfg)
+        loss_fn = fused_render_loss if (self.fused_loss and res['rgb_marched'].is_cuda) else render_loss
+        loss = loss_fn(res, target, n_global, cfg)
         loss.backward()
         self.reduce_gradients()
         if cfg['tv_after'] < global_step < cfg['tv_before'] and global_step % cfg['tv_every'] == 0:   # run.py:389-395

@@ -303,6 +303,28 @@ int dvgo_total_variation_add_grad(const float* param, float* grad, float wx, flo
                                   int64_t sC, int64_t sI, int64_t sJ, int64_t sK,
                                   int dense_mode, void* stream);
 
+/* ---------------------------------------------------------------------------------
+ * Harness glue (row H3): fused training loss, view-direction embedding, multi-tensor Adam.
+ *
+ * dvgo_loss_fwd_bwd: the loss of run.py:377-386 and its gradients in one pass.
+ *   loss = w_main * sum((rgb_marched - target)^2) / (3 n_rays_global)
+ *        + w_ent  * sum(-(p log p + (1-p) log(1-p))) / n_rays_global,  p = clamp(alphainv_last, 1e-6, 1-1e-6)
+ *        + w_per  * sum_i weights_i * |raw_rgb_i - target[ray_id_i]|^2 / n_rays_global   (weights detached)
+ *   Writes loss_out[0] (device scalar) and d loss / d {rgb_marched [N,3], alphainv_last [N], raw_rgb [M,3]}.
+ *   n_rays_global is the ray count over all ranks (data parallel).
+ * dvgo_viewdir_embed: emb [N, 3 + 6F] = cat([v, sin(v (x) freq), cos(v (x) freq)]) (lib/dvgo.py:524-525).
+ * dvgo_adam_upd_multi: plain Adam (mode 0 of dvgo_adam_upd) over up to 16 small tensors in one launch;
+ *   the pointer tables and numel are HOST arrays.
+ * --------------------------------------------------------------------------------- */
+int dvgo_loss_fwd_bwd(const float* rgb_marched, const float* alphainv_last, const float* target, int64_t N,
+                      const float* raw_rgb, const float* weights, const int64_t* ray_id, int64_t M,
+                      int64_t n_rays_global, float w_main, float w_ent, float w_per,
+                      float* g_marched, float* g_last, float* g_raw_rgb, float* loss_out, void* stream);
+int dvgo_viewdir_embed(const float* viewdirs, const float* freq, int n_freq, int64_t N, float* emb, void* stream);
+int dvgo_adam_upd_multi(float* const* params, const float* const* grads, float* const* exp_avg,
+                        float* const* exp_avg_sq, const int64_t* numel, int n_tensors, float step_size,
+                        float beta1, float beta2, float eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
