@@ -657,7 +657,7 @@ int dvgo_march_composite(const float* weights, const float* rgb, const int64_t* 
   if (n_rays < 0) return DVGO_EINVAL;
   if (n_rays == 0) return 0;
   if (!off3 || !alphainv_last || !rgb_marched) return DVGO_EINVAL;
-  if (depth && !step_id) return DVGO_EINVAL;
+  // step_id / weights / rgb may be NULL when no sample survived (M3 == 0): they are only read inside [off3[r], off3[r+1])
   if (!dvgo_fits(n_rays * 64)) return DVGO_ERANGE;
   march_composite_kernel<<<dvgo_blocks(n_rays * 64, DVGO_BLOCK), DVGO_BLOCK, 0, (hipStream_t)stream>>>(
       weights, rgb, step_id, off3, n_rays, alphainv_last, bg, rgb_marched, depth);
@@ -717,8 +717,8 @@ int dvgo_march_density_bwd(const dvgo_rec2_t* rec2, const int32_t* n2, const int
   if (n_rays < 0 || X <= 0 || Y <= 0 || Z <= 0) return DVGO_EINVAL;
   if (n_rays == 0) return 0;
   if (!rec2 || !n2 || !n_steps || !off3 || !rays_start || !rays_dir || !xyz_min ||
-      !xyz_max || !alphainv_last || !grad_weights || !grad_density)
-    return DVGO_EINVAL;
+      !xyz_max || !alphainv_last || !grad_density)
+    return DVGO_EINVAL;       // grad_weights may be NULL when M3 == 0 (it is only read for flagged samples)
   if (!n_steps_cumsum && rec_stride <= 0) return DVGO_EINVAL;
   if (!dvgo_fits(n_rays * 64)) return DVGO_ERANGE;
   const MarchParams P = make_params(xyz_min, xyz_max, stepdist, nullptr, nullptr, 0, 0, 0, X, Y, Z, 0.f,

@@ -331,7 +331,8 @@ static inline void ora_corners(const float* p, const float* xyz_min, const float
       for (int d = 0; d < 2; ++d) {  /* W / Z : w,e  */
         c->w[n] = (wz[d] * wy[b]) * wx[a];
         c->ok[n] = (ii[a] >= 0 && ii[a] < X && jj[b] >= 0 && jj[b] < Y && kk[d] >= 0 && kk[d] < Z);
-        c->off[n] = ii[a] * sX + jj[b] * sY + kk[d] * sZ;
+        /* out-of-range corners (incl. NaN / inf coordinates) are never dereferenced: keep their offset defined */
+        c->off[n] = c->ok[n] ? ii[a] * sX + jj[b] * sY + kk[d] * sZ : 0;
         ++n;
       }
 }

@@ -197,3 +197,20 @@ def test_render_viewpoints_chunked_equals_single_pass():
     np.testing.assert_allclose(rgbs[0].reshape(-1, 3), res['rgb_marched'].cpu().numpy(), atol=1e-6)
     np.testing.assert_allclose(depths[0].reshape(-1), res['depth'].cpu().numpy(), atol=1e-4)
     assert 0.0 <= rgbs.min() and rgbs.max() <= 1.0 + 1e-5
+
+
+@pytest.mark.parametrize('fused', [True, False])
+def test_batch_in_which_no_sample_survives(fused):
+    """Empty space everywhere (alpha below the threshold): M3 == 0 must flow through forward, depth and
+    backward (the renderer meets such chunks at image corners)."""
+    g = load_golden('forward_fine')
+    m = build_model(g, True, fused)
+    with torch.no_grad():
+        m.density.fill_(-20.0)
+    ro, rd, vd = cu(g['rays_o']), cu(g['rays_d']), cu(g['viewdirs'])
+    res = m(ro, rd, vd, global_step=0, near=float(g['near']), far=float(g['far']), bg=1, stepsize=0.5, render_depth=True)
+    assert res['weights'].numel() == 0 and res['raw_rgb'].shape == (0, 3)
+    assert torch.allclose(res['rgb_marched'], torch.ones_like(res['rgb_marched']))      # pure background
+    assert torch.all(res['alphainv_last'] == 1) and torch.all(res['depth'] == 0)
+    loss_fn(res, cu(g['target']), ro.shape[0], 0.001, 0.01).backward()
+    assert m.density.grad is None or float(m.density.grad.abs().sum()) == 0.0
