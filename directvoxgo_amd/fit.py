@@ -49,3 +49,60 @@ def fit_stage(model, rays_o, rays_d, viewdirs, target, cfg_train, render_kwargs,
         if log_every and global_step % log_every == 0:
             print(f'fit_stage: iter {global_step:6d} loss {float(loss):.6f} psnr {sum(psnrs[-log_every:]) / log_every:.2f}')
     return psnrs
+
+
+# ----------------------------------------------------------------------------------------------
+# Scene bounds and the coarse -> fine flow (run.py:155-196, 440-492)
+# ----------------------------------------------------------------------------------------------
+@torch.no_grad()
+def compute_bbox_by_cam_frustrm(HW, Ks, poses, near, far, ndc=False, inverse_y=False, flip_x=False, flip_y=False,
+                                device='cpu'):
+    """Axis-aligned box around every training ray's near and far point (run.py:155-173)."""
+    from .render import get_rays_of_a_view
+    import numpy as np
+    lo = torch.full((3,), float('inf'), device=device)
+    hi = -lo
+    for (H, W), K, c2w in zip(HW, Ks, poses):
+        c2w = torch.as_tensor(np.asarray(c2w), dtype=torch.float32, device=device)
+        rays_o, rays_d, viewdirs = get_rays_of_a_view(int(H), int(W), K, c2w, ndc, inverse_y, flip_x, flip_y)
+        step = rays_d if ndc else viewdirs
+        for t in (near, far):
+            pts = (rays_o + step * t).reshape(-1, 3)
+            lo = torch.minimum(lo, pts.amin(0))
+            hi = torch.maximum(hi, pts.amax(0))
+    return lo, hi
+
+
+@torch.no_grad()
+def compute_bbox_by_coarse_geo(model, thres):
+    """Tight box around the voxels the coarse model considers occupied (run.py:175-196)."""
+    ws = model.density.shape[2:]
+    dev = model.density.device
+    interp = torch.stack(torch.meshgrid(*[torch.linspace(0, 1, int(n), device=dev) for n in ws], indexing='ij'), -1)
+    xyz_min, xyz_max = model.xyz_min.to(dev), model.xyz_max.to(dev)
+    dense_xyz = xyz_min * (1 - interp) + xyz_max * interp
+    alpha = model.activate_density(model.grid_sampler(dense_xyz, model.density))
+    active = dense_xyz[alpha > thres]
+    return active.amin(0), active.amax(0)
+
+
+def train_two_stage(model_class, xyz_min, xyz_max, rays_o, rays_d, viewdirs, target, render_kwargs, coarse_model, fine_model,
+                    coarse_train, fine_train, ckpt_dir, bbox_thres=1e-3, world_bound_scale=1.05, device='cuda'):
+    """The reference's train() flow (run.py:440-492) on in-memory rays: coarse stage -> checkpoint ->
+    bounds from the coarse geometry -> fine stage whose occupancy grid is seeded from the coarse checkpoint
+    (mask_cache_path) and whose batches only contain rays that hit it.  Returns (fine_model, psnr lists)."""
+    import os
+    from .checkpoint import save_checkpoint
+    coarse = model_class(xyz_min, xyz_max, **coarse_model).to(device)
+    ps_c = fit_stage(coarse, rays_o, rays_d, viewdirs, target, coarse_train, render_kwargs, n_iters=coarse_train['N_iters'])
+    ckpt = os.path.join(ckpt_dir, 'coarse_last.tar')
+    save_checkpoint(ckpt, coarse, None, coarse_train['N_iters'])
+    lo, hi = compute_bbox_by_coarse_geo(coarse, bbox_thres)
+    shift = (hi - lo) * (world_bound_scale - 1) / 2                                   # run.py:476-479 (bound scale)
+    lo, hi = (lo - shift).cpu(), (hi + shift).cpu()
+    fine = model_class(lo, hi, mask_cache_path=ckpt, **fine_model).to(device)
+    hit = torch.cat([fine.hit_coarse_geo(rays_o=rays_o[i:i + 65536], rays_d=rays_d[i:i + 65536], **render_kwargs)
+                     for i in range(0, rays_o.shape[0], 65536)])                      # 'in_maskcache' ray sampler
+    ps_f = fit_stage(fine, rays_o[hit], rays_d[hit], viewdirs[hit], target[hit], fine_train, render_kwargs,
+                     n_iters=fine_train['N_iters'], num_voxels_final=fine_model['num_voxels'])
+    return fine, (ps_c, ps_f)
