@@ -359,6 +359,42 @@ def gen_masked_adam(R):
     save('masked_adam', **out)
 
 
+def gen_trajectory(R):
+    """H3: three optimisation steps of the reference pieces -- DirectVoxGO.forward (lib/dvgo.py), the loss of
+    run.py:377-386 (restated in _loss), MaskedAdam with skip_zero_grad on the grids (lib/masked_adam.py,
+    lib/utils.py:20-48) and the per-step lr decay of run.py:401-406 -- natives = oracle.  Parameters after
+    every step are the fixture."""
+    rng = np.random.default_rng(910)
+    m, mn, mx = _scene(R, rng, fine=True, nvox=12 ** 3, width=16)
+    ro, rd, vd = lego_like_rays(R, rng, n_views=3, H=6, W=6, focal=6 * 1111.11 / 800 * 3.0, radius=3.0)
+    N = ro.shape[0]
+    target = torch.from_numpy(rng.random((N, 3)).astype(np.float32))
+    rk = dict(near=0.5, far=6.0, bg=1, stepsize=0.5)
+    out = dict(xyz_min=mn, xyz_max=mx, world_size=m.world_size.numpy(), density0=m.density.detach().clone(),
+               k00=m.k0.detach().clone(), mask=m.mask_cache.mask, rays_o=ro, rays_d=rd, viewdirs=vd, target=target,
+               near=rk['near'], far=rk['far'], stepsize=rk['stepsize'], fast_color_thres=np.float64(m.fast_color_thres))
+    for k, v in m.rgbnet.state_dict().items():
+        out['rgbnet0_' + k] = v.detach().clone()
+    groups = [{'params': [m.density], 'lr': 0.1, 'skip_zero_grad': True}, {'params': [m.k0], 'lr': 0.1, 'skip_zero_grad': True},
+              {'params': list(m.rgbnet.parameters()), 'lr': 1e-3, 'skip_zero_grad': False}]
+    opt = R.masked_adam.MaskedAdam(groups)
+    decay = 0.1 ** (1 / (20 * 1000))
+    for step in range(1, 4):
+        res = m(ro, rd, vd, global_step=step, **rk)
+        opt.zero_grad(set_to_none=True)
+        loss = _loss(res, target, N)
+        loss.backward()
+        opt.step()
+        for g in opt.param_groups:
+            g['lr'] = g['lr'] * decay
+        out[f'loss{step}'] = loss.detach().clone()
+        out[f'density{step}'] = m.density.detach().clone()
+        out[f'k0{step}'] = m.k0.detach().clone()
+        for k, v in m.rgbnet.state_dict().items():
+            out[f'rgbnet{step}_' + k] = v.detach().clone()
+    save('trajectory', **out)
+
+
 def gen_rays(R):
     """Ray generator pin (lib/ray_utils.py:9-47,80-85 + lib/load_blender.py:37-42)."""
     rng = np.random.default_rng(809)
@@ -381,6 +417,7 @@ def main():
         gen_mpi_forward(R)
         gen_voxel_count_views(R)
         gen_masked_adam(R)
+        gen_trajectory(R)
         gen_rays(R)
     finally:
         shutil.rmtree(R.scratch, ignore_errors=True)

@@ -103,3 +103,37 @@ def test_two_stage_flow_coarse_to_fine(tmp_path):
     assert np.mean(ps_f[-30:]) > np.mean(ps_f[:10]) + 3.0               # and so does the fine stage on top of it
     assert 0.0 < float(fine.mask_cache.mask.float().mean()) < 0.9       # occupancy seeded from the coarse checkpoint
     assert bool((fine.xyz_max.cpu() - fine.xyz_min.cpu() < sc['xyz_max'].cpu() - sc['xyz_min'].cpu() + 1e-3).all())
+
+
+@pytest.mark.parametrize('fused', [True, False])
+def test_three_step_trajectory_matches_reference_pieces(fused):
+    """H3 pin: parameters after each of three optimisation steps equal the trajectory produced by the
+    reference's own DirectVoxGO.forward + MaskedAdam (+ the run.py loss) over the oracle natives."""
+    from conftest import load_golden
+    from directvoxgo_amd.dvgo import DirectVoxGO
+    from directvoxgo_amd.train import FINE_TRAIN, TrainStep
+    g = load_golden('trajectory')
+    nv = int(np.prod(g['world_size']))
+    m = DirectVoxGO(g['xyz_min'], g['xyz_max'], num_voxels=nv, num_voxels_base=nv, alpha_init=1e-2,
+                    fast_color_thres=float(g['fast_color_thres']), rgbnet_dim=12, rgbnet_depth=3, rgbnet_width=16,
+                    viewbase_pe=4, fused=fused)
+    with torch.no_grad():
+        m.density.copy_(torch.from_numpy(g['density0'])); m.k0.copy_(torch.from_numpy(g['k00']))
+        m.mask_cache.mask.copy_(torch.from_numpy(g['mask']))
+        m.rgbnet.load_state_dict({k[len('rgbnet0_'):]: torch.from_numpy(v) for k, v in g.items() if k.startswith('rgbnet0_')})
+    m = m.cuda()
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    rk = dict(near=float(g['near']), far=float(g['far']), bg=1, stepsize=float(g['stepsize']))
+    step = TrainStep(m, dict(FINE_TRAIN), rk)
+    ro, rd, vd, tgt = cu(g['rays_o']), cu(g['rays_d']), cu(g['viewdirs']), cu(g['target'])
+    for s in (1, 2, 3):
+        loss = step(ro, rd, vd, tgt, global_step=s)
+        np.testing.assert_allclose(float(loss), float(g[f'loss{s}']), rtol=2e-5)
+        # Adam normalises the update to ~lr per element, so parameters are compared with an absolute
+        # tolerance well below one update (lr = 0.1 for the grids, 1e-3 for the MLP)
+        np.testing.assert_allclose(m.density.detach().cpu().numpy(), g[f'density{s}'], atol=2e-3)
+        np.testing.assert_allclose(m.k0.detach().cpu().numpy(), g[f'k0{s}'], atol=2e-3)
+        for k, p in m.rgbnet.state_dict().items():
+            np.testing.assert_allclose(p.cpu().numpy(), g[f'rgbnet{s}_' + k], atol=5e-5)
+        # and the set of updated voxels (masked Adam: grad != 0) is identical
+        assert np.array_equal(m.density.detach().cpu().numpy() != g['density0'], g[f'density{s}'] != g['density0'])
