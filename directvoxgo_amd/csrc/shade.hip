@@ -337,19 +337,24 @@ shade_bwd_kernel(const float* __restrict__ g_rgb, const float* __restrict__ rgb,
 //   A[i = out feature][k = row]  : lane (i, h) reads G[row = 2s + h][f0 + i]
 //   B[k = row][j = in feature]   : lane (j, h) reads H[row = 2s + h][f0' + j]
 // i.e. consecutive lanes read consecutive floats of one row: no transpose anywhere.  Each 32-row tile
-// is staged once into LDS with 16-byte coalesced loads (software-prefetched one tile ahead) and the
-// MFMA operands are conflict-free ds_read_b32.
+// is copied once into LDS by LDS-DMA, one tile ahead (double buffer), and the MFMA operands are
+// conflict-free ds_read_b32.
 // The 4 waves of a workgroup walk the SAME 32-row tiles and split the output features between them
-// (wave w owns out-feature tile w), which keeps every wave's persistent accumulators at 112 registers
-// (dW2: 4 tiles, dW1: 2 tiles, dW3: 1 tile); the B operands are shared through L1.
+// (wave w owns out-feature tile w), which keeps every wave's persistent accumulators at 80 registers
+// (dW2: 4 tiles, dW1: 1 tile; dW3 and the <= 8 trailing input columns of dW1 are a few VALU FMAs per
+// row instead of mostly-empty 32-wide MFMA tiles).
 // Each workgroup writes its partial sums to part[blockIdx]; the caller sums over workgroups.
 // ----------------------------------------------------------------------------------
 template <int WIDTH>
 struct ShadeWgradLds {
-  float g1[32][WIDTH], g2[32][WIDTH], h1[32][WIDTH], h2[32][WIDTH];
-  float x[32][64];
-  float gz[32][4];
+  // single-buffered 32-row tiles (74 KB): two workgroups share a CU and cover each other's load phase
+  float g1[1][32][WIDTH], g2[1][32][WIDTH], h1[1][32][WIDTH], h2[1][32][WIDTH];
+  float x[1][32][64];
+  float gz[1][32][4];
 };
+
+typedef const __attribute__((address_space(1))) void* dvgo_gptr_t;
+typedef __attribute__((address_space(3))) void* dvgo_lptr_t;
 
 template <int WIDTH>
 __global__ void __launch_bounds__(256)
@@ -361,118 +366,122 @@ shade_wgrad_kernel(const float* __restrict__ G1, const float* __restrict__ G2, c
   static_assert(T == 4, "one out-feature tile per wave");
   __shared__ __attribute__((aligned(16))) ShadeWgradLds<WIDTH> L;
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, j = lane & 31, w = tid >> 6;
-  f32x16 aW2[T], aW1[2], aW3;
+  f32x16 aW2[T], aW1;
+  float vW3[3] = {0.0f, 0.0f, 0.0f};     // dW3[c][32w + j]: 3 outputs only -> VALU, not a 32-wide MFMA tile
+  float vW1[8];                            // dW1[32w + j][32 + kk], kk < d_in - 32 (<= 8 columns) -> VALU
 #pragma unroll
   for (int t = 0; t < T; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) aW2[t][r] = 0.0f;
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int r = 0; r < 16; ++r) aW1[r] = 0.0f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) aW1[t][r] = 0.0f;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) aW3[r] = 0.0f;
-  float sb1 = 0.0f, sb2 = 0.0f, sb3 = 0.0f;      // bias gradients: column sums of the A operands
+  for (int kk = 0; kk < 8; ++kk) vW1[kk] = 0.0f;
+  float sb1 = 0.0f, sb2 = 0.0f, gz_acc = 0.0f;   // bias gradients: column sums of the A operands / of gz
   const int d_in = n_view + E;
   const int64_t n_tiles = (M + 31) / 32;
 
-  // staging registers for the next tile: 4 matrices x 4 float4 per thread, 8 x-values, <= 1 gz value.
-  // (Written inline with unconditional, address-clamped loads: conditional loads or lambdas here made
-  //  hipcc keep the staging arrays in scratch and wait for every load individually.)
-  float4 pg1[4], pg2[4], ph1[4], ph2[4];
+  // The four 32 x WIDTH operand tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging
+  // registers, 1 KB = two 512-B rows per wave instruction, LDS image == the row-major global image), one
+  // tile at a time; the second workgroup resident on the CU computes meanwhile.  Rows past M are read from a
+  // clamped row and masked at operand read.
+  // The small assembled X tile and gz travel through registers.
   float px[8], pgz;
-#define SHADE_WGRAD_PREFETCH(TILE)                                                                   \
-  {                                                                                                  \
-    const int64_t r0_ = (TILE) * 32;                                                                 \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                  \
-      const int idx = tid + 256 * i;                                                                 \
-      const int64_t row = r0_ + (idx >> 5);                                                          \
-      const int64_t off = (row < M ? row : M - 1) * WIDTH + 4 * (idx & 31);                          \
-      pg1[i] = *reinterpret_cast<const float4*>(G1 + off);                                           \
-      pg2[i] = *reinterpret_cast<const float4*>(G2 + off);                                           \
-      ph1[i] = *reinterpret_cast<const float4*>(H1 + off);                                           \
-      ph2[i] = *reinterpret_cast<const float4*>(H2 + off);                                           \
-    }                                                                                                \
-    {                                                                                                \
-      const int64_t row = r0_ + (tid >> 3);                                                          \
-      const int64_t rc = row < M ? row : M - 1;                                                      \
-      const float* fr = feat + rc * C + c_view0;                                                     \
-      const float* er = emb + ray_id[rc] * E - n_view;                                               \
-      _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                \
-        const int k = (tid & 7) + 8 * i;                                                             \
-        const int kc = k < d_in ? k : d_in - 1;                                                      \
-        const float v = (kc < n_view) ? fr[kc] : er[kc];                                             \
-        px[i] = (k < d_in) ? v : 0.0f;                                                               \
-      }                                                                                              \
-    }                                                                                                \
-    {                                                                                                \
-      const int64_t row = r0_ + ((tid & 127) >> 2);                                                  \
-      const int64_t rc = row < M ? row : M - 1;                                                      \
-      const int c = (tid & 3) < 3 ? (tid & 3) : 0;                                                   \
-      pgz = gz[rc * 3 + c];                                                                          \
-    }                                                                                                \
+#define SHADE_WGRAD_DMA(TILE, BUF)                                                                              \
+  {                                                                                                             \
+    const int64_t r0_ = (TILE) * 32;                                                                            \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                             \
+      const int rl = 8 * w + 2 * i;                     /* this wave instruction covers rows rl, rl + 1 */      \
+      const int64_t row = r0_ + rl + h;                                                                         \
+      const int64_t off = (row < M ? row : M - 1) * WIDTH + 4 * j;                                              \
+      __builtin_amdgcn_global_load_lds((dvgo_gptr_t)(G1 + off), (dvgo_lptr_t)&L.g1[BUF][rl][0], 16, 0, 0);     \
+      __builtin_amdgcn_global_load_lds((dvgo_gptr_t)(G2 + off), (dvgo_lptr_t)&L.g2[BUF][rl][0], 16, 0, 0);     \
+      __builtin_amdgcn_global_load_lds((dvgo_gptr_t)(H1 + off), (dvgo_lptr_t)&L.h1[BUF][rl][0], 16, 0, 0);     \
+      __builtin_amdgcn_global_load_lds((dvgo_gptr_t)(H2 + off), (dvgo_lptr_t)&L.h2[BUF][rl][0], 16, 0, 0);     \
+    }                                                                                                           \
+    {                                                                                                           \
+      const int64_t row = r0_ + (tid >> 3);                                                                     \
+      const int64_t rc = row < M ? row : M - 1;                                                                 \
+      const float* fr = feat + rc * C + c_view0;                                                                \
+      const float* er = emb + ray_id[rc] * E - n_view;                                                          \
+      _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                           \
+        const int k = (tid & 7) + 8 * i;                                                                        \
+        const int kc = k < d_in ? k : d_in - 1;                                                                 \
+        const float v = (kc < n_view) ? fr[kc] : er[kc];                                                        \
+        px[i] = (k < d_in && row < M) ? v : 0.0f;                                                               \
+      }                                                                                                         \
+    }                                                                                                           \
+    {                                                                                                           \
+      const int64_t row = r0_ + ((tid & 127) >> 2);                                                             \
+      const int64_t rc = row < M ? row : M - 1;                                                                 \
+      const int c = (tid & 3) < 3 ? (tid & 3) : 0;                                                              \
+      pgz = ((tid & 3) < 3 && row < M) ? gz[rc * 3 + c] : 0.0f;                                                 \
+    }                                                                                                           \
   }
 
-  int64_t tile = blockIdx.x;
-  if (tile < n_tiles) SHADE_WGRAD_PREFETCH(tile);
-  for (; tile < n_tiles; tile += gridDim.x) {
-    {   // commit the staged tile to LDS; rows past M are zeroed here (they were loaded from a clamped row)
-      const int64_t r0 = tile * 32;
+  constexpr int buf = 0;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    SHADE_WGRAD_DMA(tile, 0);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int idx = tid + 256 * i;
-        const int row = idx >> 5, c4 = 4 * (idx & 31);
-        const float m = (r0 + row < M) ? 1.0f : 0.0f;
-        *reinterpret_cast<float4*>(&L.g1[row][c4]) = make_float4(pg1[i].x * m, pg1[i].y * m, pg1[i].z * m, pg1[i].w * m);
-        *reinterpret_cast<float4*>(&L.g2[row][c4]) = make_float4(pg2[i].x * m, pg2[i].y * m, pg2[i].z * m, pg2[i].w * m);
-        *reinterpret_cast<float4*>(&L.h1[row][c4]) = ph1[i];
-        *reinterpret_cast<float4*>(&L.h2[row][c4]) = ph2[i];
-      }
-#pragma unroll
-      for (int i = 0; i < 8; ++i) L.x[tid >> 3][(tid & 7) + 8 * i] = px[i];
-      if (tid < 128) L.gz[tid >> 2][tid & 3] = ((tid & 3) < 3 && r0 + (tid >> 2) < M) ? pgz : 0.0f;
-    }
-    __syncthreads();
-    const int64_t nxt = tile + gridDim.x;
-    SHADE_WGRAD_PREFETCH(nxt < n_tiles ? nxt : tile);      // overlaps with the MFMAs below (last one is redundant)
+    for (int i = 0; i < 8; ++i) L.x[buf][tid >> 3][(tid & 7) + 8 * i] = px[i];
+    if (tid < 128) L.gz[buf][tid >> 2][tid & 3] = pgz;
+    __syncthreads();      // DMA of this tile has landed (vmcnt(0) precedes the barrier), X / gz committed
+    const int64_t r0 = tile * 32;
 #pragma unroll 4
     for (int s = 0; s < 16; ++s) {
       const int row = 2 * s + h;
-      const float a2 = L.g2[row][32 * w + j];
-      const float a1 = L.g1[row][32 * w + j];
-      const float a3 = (j < 3) ? L.gz[row][j] : 0.0f;
-      sb2 += a2; sb1 += a1; sb3 += a3;
+      const float rm = (r0 + row < M) ? 1.0f : 0.0f;
+      const float a2 = L.g2[buf][row][32 * w + j] * rm;
+      const float a1 = L.g1[buf][row][32 * w + j] * rm;
+      sb2 += a2; sb1 += a1;
+      if (j < 3) gz_acc += L.gz[buf][row][j];
 #pragma unroll
       for (int t = 0; t < T; ++t)
-        aW2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, L.h1[row][32 * t + j], aW2[t], 0, 0, 0);
-      aW1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, L.x[row][j], aW1[0], 0, 0, 0);
-      aW1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, L.x[row][32 + j], aW1[1], 0, 0, 0);
-      aW3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, L.h2[row][32 * w + j], aW3, 0, 0, 0);
+        aW2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, L.h1[buf][row][32 * t + j], aW2[t], 0, 0, 0);
+      aW1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, L.x[buf][row][j], aW1, 0, 0, 0);
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) vW1[kk] = fmaf(a1, L.x[buf][row][32 + kk], vW1[kk]);   // broadcast reads; zero past d_in
+      const float hv = L.h2[buf][row][32 * w + j];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) vW3[c] = fmaf(L.gz[buf][row][c], hv, vW3[c]);           // gz == 0 on rows past M
     }
-    __syncthreads();
+    __syncthreads();      // every wave is done with the tile before the next DMA overwrites it
   }
-#undef SHADE_WGRAD_PREFETCH
+#undef SHADE_WGRAD_DMA
   // D[row = (r&3) + 8*(r>>2) + 4*h][col = j]
   float* p = part + (int64_t)blockIdx.x * (WIDTH * WIDTH + WIDTH * 64 + 32 * WIDTH + 3 * WIDTH);
   float* pW2 = p;                          // [WIDTH out][WIDTH in]
   float* pW1 = pW2 + WIDTH * WIDTH;        // [WIDTH out][64]
-  float* pW3 = pW1 + WIDTH * 64;           // [32 (c padded)][WIDTH]
+  float* pW3 = pW1 + WIDTH * 64;           // [32 (c padded)][WIDTH], rows 0..2 written
   float* pb = pW3 + 32 * WIDTH;            // [3][WIDTH]: db1, db2, db3 (first 3 entries)
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
 #pragma unroll
     for (int t = 0; t < T; ++t) pW2[(32 * w + i) * WIDTH + 32 * t + j] = aW2[t][r];
-    pW1[(32 * w + i) * 64 + j] = aW1[0][r];
-    pW1[(32 * w + i) * 64 + 32 + j] = aW1[1][r];
-    pW3[i * WIDTH + 32 * w + j] = aW3[r];
+    pW1[(32 * w + i) * 64 + j] = aW1[r];
   }
-  // bias sums: lanes j and j+32 hold the even / odd rows of the same feature
-  sb1 += __shfl_xor(sb1, 32); sb2 += __shfl_xor(sb2, 32); sb3 += __shfl_xor(sb3, 32);
+  // VALU parts: lanes j and j+32 hold the even / odd rows
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) {
+    const float v = vW1[kk] + __shfl_xor(vW1[kk], 32);
+    if (h == 0) pW1[(32 * w + j) * 64 + 32 + kk] = v;
+  }
+  if (h == 0) {
+#pragma unroll
+    for (int kk = 8; kk < 32; ++kk) pW1[(32 * w + j) * 64 + 32 + kk] = 0.0f;
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float v = vW3[c] + __shfl_xor(vW3[c], 32);
+    if (h == 0) pW3[c * WIDTH + 32 * w + j] = v;
+  }
+  const float gz_sum = gz_acc + __shfl_xor(gz_acc, 32);   // db3[c] = sum over rows of gz[:, c] on lanes j < 3
+  sb1 += __shfl_xor(sb1, 32); sb2 += __shfl_xor(sb2, 32);
   if (h == 0) {
     pb[32 * w + j] = sb1;
     pb[WIDTH + 32 * w + j] = sb2;
-    if (w == 0) pb[2 * WIDTH + j] = sb3;
+    if (w == 0) pb[2 * WIDTH + j] = gz_sum;
   }
 }
 

@@ -11,7 +11,7 @@ import torch.nn as nn
 from . import _lib as L
 from ._lib import _i64, _int, ptr, stream_of
 
-N_PARTS = 512     # max workgroups (= partial sums) of the weight-gradient kernel: two resident per CU
+N_PARTS = 512     # max workgroups (= partial sums) of the weight-gradient kernel: two per CU (74 KB of LDS each)
 
 
 @torch.no_grad()
