@@ -14,6 +14,31 @@ from ._lib import _i64, _int, ptr, stream_of
 N_PARTS = 512     # max workgroups (= partial sums) of the weight-gradient kernel: two per CU (74 KB of LDS each)
 
 
+class defer_wgrad:
+    """Context manager: inside it, the colour head's backward only produces the data gradient and queues its
+    weight-gradient kernel; `flush()` runs the queued work and accumulates into the parameters' `.grad`.
+    The training step uses it to start the (large) grid-gradient all-reduce before the weight gradients are
+    computed, so that communication overlaps with that kernel."""
+    _active = None
+
+    def __enter__(self):
+        self.pending = []
+        defer_wgrad._active = self
+        return self
+
+    def __exit__(self, *exc):
+        defer_wgrad._active = None
+        return False
+
+    @torch.no_grad()
+    def flush(self):
+        for params, fn in self.pending:
+            for p, g in zip(params, fn()):
+                if p.requires_grad:
+                    p.grad = g if p.grad is None else p.grad + g
+        self.pending = []
+
+
 @torch.no_grad()
 def viewdir_embed(viewdirs, viewfreq):
     """cat([v, sin(v (x) freq), cos(v (x) freq)]) of lib/dvgo.py:524-525 in one launch -> [N, 3 + 6F]."""
@@ -62,6 +87,7 @@ class _Shade(torch.autograd.Function):
         if train:
             ctx.save_for_backward(feat, emb, ray_id, W1, W2, W3, rgb, H1, H2, masks)
             ctx.diffuse = diffuse
+            ctx.params = (W1, b1, W2, b2, W3, b3)
         return rgb
 
     @staticmethod
@@ -75,24 +101,33 @@ class _Shade(torch.autograd.Function):
         G1 = torch.empty_like(H1)
         G2 = torch.empty_like(H2)
         gz = torch.empty_like(rgb)
-        psize = width * width + width * 64 + 32 * width + 3 * width
-        n_parts = max(1, min(N_PARTS, (M + 511) // 512))      # >= 16 row tiles per workgroup on small batches
-        part = torch.empty((n_parts, psize), dtype=torch.float32, device=feat.device)
         with torch.cuda.device_of(feat):
             L.call('dvgo_shade_bwd', ptr(g_rgb.contiguous()), ptr(rgb), ptr(masks), _i64(M), ptr(W1.contiguous()),
                    ptr(W2.contiguous()), ptr(W3.contiguous()), _int(width), _int(d_in), _int(C), _int(1 if diffuse else 0),
                    ptr(g_feat), ptr(G1), ptr(G2), ptr(gz), stream_of(feat))
-            L.call('dvgo_shade_wgrad', ptr(G1), ptr(G2), ptr(gz), ptr(H1), ptr(H2), ptr(feat), _int(C), ptr(emb),
-                   _int(emb.shape[1]), ptr(ray_id), _i64(M), _int(width), _int(1 if diffuse else 0), _int(n_parts),
-                   ptr(part), stream_of(feat))
-        tot = part.sum(0)
-        o = 0
-        gW2 = tot[o:o + width * width].view(width, width); o += width * width
-        gW1 = tot[o:o + width * 64].view(width, 64)[:, :d_in]; o += width * 64
-        gW3 = tot[o:o + 32 * width].view(32, width)[:3]; o += 32 * width
-        gb1, gb2, gb3 = tot[o:o + width], tot[o + width:o + 2 * width], tot[o + 2 * width:o + 2 * width + 3]
-        return (g_feat if ctx.needs_input_grad[0] else None, None, None, gW1.contiguous(), gb1, gW2, gb2,
-                gW3.contiguous(), gb3, None)
+
+        def wgrad():
+            n_parts = max(1, min(N_PARTS, (M + 511) // 512))      # >= 16 row tiles per workgroup on small batches
+            psize = width * width + width * 64 + 32 * width + 3 * width
+            part = torch.empty((n_parts, psize), dtype=torch.float32, device=feat.device)
+            with torch.cuda.device_of(feat):
+                L.call('dvgo_shade_wgrad', ptr(G1), ptr(G2), ptr(gz), ptr(H1), ptr(H2), ptr(feat), _int(C), ptr(emb),
+                       _int(emb.shape[1]), ptr(ray_id), _i64(M), _int(width), _int(1 if diffuse else 0), _int(n_parts),
+                       ptr(part), stream_of(feat))
+            tot = part.sum(0)
+            o = 0
+            gW2 = tot[o:o + width * width].view(width, width); o += width * width
+            gW1 = tot[o:o + width * 64].view(width, 64)[:, :d_in]; o += width * 64
+            gW3 = tot[o:o + 32 * width].view(32, width)[:3]; o += 32 * width
+            gb1, gb2, gb3 = tot[o:o + width], tot[o + width:o + 2 * width], tot[o + 2 * width:o + 2 * width + 3]
+            return gW1.contiguous(), gb1, gW2, gb2, gW3.contiguous(), gb3
+
+        gf = g_feat if ctx.needs_input_grad[0] else None
+        if defer_wgrad._active is not None:
+            defer_wgrad._active.pending.append((ctx.params, wgrad))
+            return (gf, None, None, None, None, None, None, None, None, None)
+        gW1, gb1, gW2, gb2, gW3, gb3 = wgrad()
+        return (gf, None, None, gW1, gb1, gW2, gb2, gW3, gb3, None)
 
 
 def shade(rgbnet, feat, emb, ray_id, diffuse):

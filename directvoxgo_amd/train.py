@@ -19,6 +19,7 @@ import torch.distributed as dist
 import torch.nn as nn
 
 from .masked_adam import MaskedAdam
+from .shade import defer_wgrad
 
 def flat_view(t):
     """1-D view of a dense tensor's memory (no copy): collectives want plain contiguous buffers, and the
@@ -131,20 +132,27 @@ class TrainStep:
         self.decay_factor = 0.1 ** (1 / (cfg_train['lrate_decay'] * 1000))
         self._small = [p for n, p in model.named_parameters() if n not in ('density', 'k0') and p.requires_grad]
 
-    def reduce_gradients(self):
-        """Sum the per-rank gradients (section 8e).  Two large collectives (the grids are reduced in
-        place, no staging copy) and one flat bucket for the MLP."""
+    def reduce_grids_async(self):
+        """Start the sum of the per-rank grid gradients (section 8e): two large collectives, in place on the
+        gradients' own memory.  Returns the handles to wait on."""
+        works = []
         if self.world == 1:
-            return
+            return works
         for p in (self.model.density, self.model.k0):
             if p.grad is not None:
                 flat = flat_view(p.grad)
-                if flat is not None:                  # in place on the gradient's own memory
-                    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg)
+                if flat is not None:
+                    works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
                 else:                                 # exotic strides: staged through a contiguous copy
                     tmp = p.grad.contiguous()
                     dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=self.pg)
                     p.grad.copy_(tmp)
+        return works
+
+    def reduce_small(self):
+        """One flat bucket for the handful of MLP gradients."""
+        if self.world == 1:
+            return
         small = [p for p in self._small if p.grad is not None]
         if small:
             flat = torch.cat([p.grad.reshape(-1) for p in small])
@@ -163,8 +171,15 @@ class TrainStep:
         self.optimizer.zero_grad(set_to_none=True)
         loss_fn = fused_render_loss if (self.fused_loss and res['rgb_marched'].is_cuda) else render_loss
         loss = loss_fn(res, target, n_global, cfg)
-        loss.backward()
-        self.reduce_gradients()
+        # backward order: ... colour-head data gradient -> grid scatters; the colour head's weight-gradient
+        # kernel is deferred until the grid all-reduce has been started, so RCCL overlaps with it
+        with defer_wgrad() as deferred:
+            loss.backward()
+        works = self.reduce_grids_async()
+        deferred.flush()
+        self.reduce_small()
+        for wk in works:
+            wk.wait()
         if cfg['tv_after'] < global_step < cfg['tv_before'] and global_step % cfg['tv_every'] == 0:   # run.py:389-395
             dense = global_step < cfg['tv_dense_before']
             if cfg['weight_tv_density'] > 0:

@@ -380,3 +380,26 @@ def test_multi_tensor_adam_equals_single_launches():
         oa.step(); ob.step()
     for x, y in zip(pa, pb):
         np.testing.assert_allclose(x.detach().cpu().numpy(), y.detach().cpu().numpy(), rtol=1e-5, atol=1e-7)
+
+
+def test_deferred_wgrad_gives_identical_parameter_gradients():
+    """shade.defer_wgrad (used by TrainStep to overlap the grid all-reduce with the weight-gradient kernel)."""
+    from directvoxgo_amd.dvgo import make_rgbnet
+    from directvoxgo_amd.shade import defer_wgrad, shade
+    torch.manual_seed(5)
+    M, N = 50000, 64
+    net = make_rgbnet(36, 128, 3).cuda()
+    feat = torch.randn(M, 12, device='cuda', requires_grad=True)
+    emb = torch.randn(N, 27, device='cuda')
+    ray_id = torch.sort(torch.randint(N, (M,), device='cuda'))[0]
+    go = torch.randn(M, 3, device='cuda')
+    shade(net, feat, emb, ray_id, True).backward(go)
+    ref = [p.grad.clone() for p in net.parameters()]; gf = feat.grad.clone()
+    net.zero_grad(set_to_none=True); feat.grad = None
+    with defer_wgrad() as d:
+        shade(net, feat, emb, ray_id, True).backward(go)
+        assert all(p.grad is None for p in net.parameters()) and len(d.pending) == 1
+    d.flush()
+    assert torch.equal(feat.grad, gf)
+    for p, r in zip(net.parameters(), ref):
+        assert torch.allclose(p.grad, r, rtol=1e-5, atol=1e-6)
