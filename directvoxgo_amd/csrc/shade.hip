@@ -24,6 +24,8 @@
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
+static int g_shade_experiment = 0;   // timing experiments only (tools/): bit 0 = skip G1/G2 stores in shade_bwd
+
 // Saved activations / gradients are plain row-major [M, features]: in the accumulator layout a lane owns
 // 4 consecutive features per register quad, i.e. one 16-byte piece of its row.
 // one workgroup per CU (the permuted weights take 86 KB of LDS); 8 wavefronts = 2 per SIMD
@@ -228,7 +230,8 @@ __global__ void __launch_bounds__(SHADE_THREADS)
 shade_bwd_kernel(const float* __restrict__ g_rgb, const float* __restrict__ rgb,
                  const unsigned long long* __restrict__ masks, int64_t M, const float* __restrict__ W1, const float* __restrict__ W2,
                  const float* __restrict__ W3, int D_in, int C, int c_view0, int n_view,
-                 float* __restrict__ g_feat, float* __restrict__ G1, float* __restrict__ G2, float* __restrict__ gz_out) {
+                 float* __restrict__ g_feat, float* __restrict__ G1, float* __restrict__ G2, float* __restrict__ gz_out,
+                 int experiment) {
   constexpr int T = WIDTH / 32;
   __shared__ ShadeBwdLds<WIDTH> L;
   {
@@ -288,7 +291,7 @@ shade_bwd_kernel(const float* __restrict__ g_rgb, const float* __restrict__ rgb,
           o[e] = ((m2 >> (16 * t2 + r)) & 1ull) ? v : 0.0f;   // gz == 0 on rows past M, so o == 0 there
           g2[t2][r] = o[e];
         }
-        if (valid) *reinterpret_cast<float4*>(G2 + row * WIDTH + f) = make_float4(o[0], o[1], o[2], o[3]);
+        if (valid && !(experiment & 1)) *reinterpret_cast<float4*>(G2 + row * WIDTH + f) = make_float4(o[0], o[1], o[2], o[3]);
       }
     }
     f32x16 gx;
@@ -313,7 +316,7 @@ shade_bwd_kernel(const float* __restrict__ g_rgb, const float* __restrict__ rgb,
         acc[4 * q + 1] = (mb & 2u) ? acc[4 * q + 1] : 0.0f;
         acc[4 * q + 2] = (mb & 4u) ? acc[4 * q + 2] : 0.0f;
         acc[4 * q + 3] = (mb & 8u) ? acc[4 * q + 3] : 0.0f;
-        if (valid)
+        if (valid && !(experiment & 1))
           *reinterpret_cast<float4*>(G1 + row * WIDTH + f) =
               make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
       }
@@ -512,6 +515,8 @@ int dvgo_shade_fwd(const float* feat, int C, const float* emb, int E, const int6
   return 0;
 }
 
+int dvgo_shade_experiment(int flags) { g_shade_experiment = flags; return 0; }
+
 int dvgo_shade_bwd(const float* g_rgb, const float* rgb, const uint64_t* masks, int64_t M,
                    const float* W1, const float* W2, const float* W3, int width, int d_in, int C, int diffuse,
                    float* g_feat, float* G1, float* G2, float* gz, void* stream) {
@@ -526,10 +531,10 @@ int dvgo_shade_bwd(const float* g_rgb, const float* rgb, const uint64_t* masks, 
   int blocks = (int)((n_tiles + SHADE_WAVES - 1) / SHADE_WAVES < 256 ? (n_tiles + SHADE_WAVES - 1) / SHADE_WAVES : 256);
   if (diffuse)
     shade_bwd_kernel<128, true><<<blocks, SHADE_THREADS, 0, s>>>(g_rgb, rgb, (const unsigned long long*)masks, M, W1, W2, W3, d_in, C, c_view0,
-                                                                 n_view, g_feat, G1, G2, gz);
+                                                                 n_view, g_feat, G1, G2, gz, g_shade_experiment);
   else
     shade_bwd_kernel<128, false><<<blocks, SHADE_THREADS, 0, s>>>(g_rgb, rgb, (const unsigned long long*)masks, M, W1, W2, W3, d_in, C, c_view0,
-                                                                  n_view, g_feat, G1, G2, gz);
+                                                                  n_view, g_feat, G1, G2, gz, g_shade_experiment);
   DVGO_LAUNCH_CHECK();
   return 0;
 }
