@@ -169,6 +169,40 @@ march_density_kernel(const float* __restrict__ rays_start, const float* __restri
 }
 
 // ----------------------------------------------------------------------------------
+// hit test: does a ray have at least one in-box sample in known-occupied space?  Fused form of
+// DirectVoxGO.hit_coarse_geo (lib/dvgo.py:412-423: sample_pts_on_rays + boolean compaction + maskcache_lookup
+// + index_put), one wavefront per ray, nothing materialised.  Used to pre-filter the training rays
+// (lib/ray_utils.py:145-183 walks every pixel of every training image through it).
+// ----------------------------------------------------------------------------------
+__global__ void __launch_bounds__(DVGO_BLOCK)
+march_hit_kernel(const float* __restrict__ rays_start, const float* __restrict__ rays_dir,
+                 const int64_t* __restrict__ n_steps, int64_t n_rays, const uint8_t* __restrict__ mask, MarchParams P,
+                 uint8_t* __restrict__ hit) {
+  const int64_t ray = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (ray >= n_rays) return;
+  const int ns = __builtin_amdgcn_readfirstlane((int)n_steps[ray]);
+  const float sx = rays_start[3 * ray], sy = rays_start[3 * ray + 1], sz = rays_start[3 * ray + 2];
+  const float dx = rays_dir[3 * ray], dy = rays_dir[3 * ray + 1], dz = rays_dir[3 * ray + 2];
+  bool any = false;
+  for (int base = 0; base < ns && !any; base += 64) {
+    const int step = base + lane;
+    const float dist = march_dist(P.stepdist, step);
+    const float px = fmaf(dx, dist, sx), py = fmaf(dy, dist, sy), pz = fmaf(dz, dist, sz);
+    bool keep = (step < ns) && !((P.mnx > px) | (P.mny > py) | (P.mnz > pz) | (P.mxx < px) | (P.mxy < py) | (P.mxz < pz));
+    if (keep) {
+      const int i = (int)roundf(fmaf(px, P.scx, P.shx));
+      const int j = (int)roundf(fmaf(py, P.scy, P.shy));
+      const int k = (int)roundf(fmaf(pz, P.scz, P.shz));
+      keep = (0 <= i) & (i < P.mX) & (0 <= j) & (j < P.mY) & (0 <= k) & (k < P.mZ);
+      if (keep) keep = mask[((int64_t)i * P.mY + j) * P.mZ + k] != 0;
+    }
+    any = __ballot(keep) != 0ull;
+  }
+  if (lane == 0) hit[ray] = any ? 1 : 0;
+}
+
+// ----------------------------------------------------------------------------------
 // march_gather: flat over M3.  C4 = C/4 channel vectors when the grid is channels-last.
 // ----------------------------------------------------------------------------------
 template <int CVEC>   // CVEC > 0: channels-last, C == 4*CVEC, 16-B aligned ; 0: generic strides
@@ -616,6 +650,22 @@ int dvgo_march_density(const float* rays_start, const float* rays_dir, const int
   march_density_kernel<<<dvgo_blocks(n_rays * 64, DVGO_BLOCK), DVGO_BLOCK, 0, (hipStream_t)stream>>>(
       rays_start, rays_dir, n_steps, n_steps_cumsum, rec_stride, n_rays, mask, density, P, rec2, rec3, n2, n3,
       alphainv_last);
+  DVGO_LAUNCH_CHECK();
+  return 0;
+}
+
+int dvgo_march_hit(const float* rays_start, const float* rays_dir, const int64_t* n_steps, int64_t n_rays,
+                   const float* xyz_min, const float* xyz_max, float stepdist, const uint8_t* mask, int mX, int mY,
+                   int mZ, const float* xyz2ijk_scale, const float* xyz2ijk_shift, uint8_t* hit, void* stream) {
+  if (n_rays < 0) return DVGO_EINVAL;
+  if (n_rays == 0) return 0;
+  if (!rays_start || !rays_dir || !n_steps || !xyz_min || !xyz_max || !mask || !xyz2ijk_scale || !xyz2ijk_shift || !hit ||
+      mX <= 0 || mY <= 0 || mZ <= 0)
+    return DVGO_EINVAL;
+  if (!dvgo_fits(n_rays * 64)) return DVGO_ERANGE;
+  const MarchParams P = make_params(xyz_min, xyz_max, stepdist, xyz2ijk_scale, xyz2ijk_shift, mX, mY, mZ, 1, 1, 1, 0.f, 0.f, 0.f);
+  march_hit_kernel<<<dvgo_blocks(n_rays * 64, DVGO_BLOCK), DVGO_BLOCK, 0, (hipStream_t)stream>>>(
+      rays_start, rays_dir, n_steps, n_rays, mask, P, hit);
   DVGO_LAUNCH_CHECK();
   return 0;
 }

@@ -22,7 +22,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import render_utils as render_utils_hip
-from .fused import MarchConfig, composite, composite_depth, fused_march
+from .fused import MarchConfig, composite, composite_depth, fused_hit, fused_march
 from .ops import Alphas2Weights, MaskCache, Raw2Alpha, grid_sample, segment_coo, total_variation_add_grad
 from .shade import shade, viewdir_embed
 
@@ -278,6 +278,8 @@ class DirectVoxGO(nn.Module):
         shape = rays_o.shape[:-1]
         rays_o = rays_o.reshape(-1, 3).contiguous()
         rays_d = rays_d.reshape(-1, 3).contiguous()
+        if self.fused and self.mask_cache is not None:
+            return fused_hit(rays_o, rays_d, self._march_cfg(near, far, stepsize)).reshape(shape)
         stepdist = stepsize * self.voxel_size
         ray_pts, mask_outbbox, ray_id = render_utils_hip.sample_pts_on_rays(
             rays_o, rays_d, self.xyz_min, self.xyz_max, near, far, stepdist)[:3]

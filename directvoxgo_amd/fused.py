@@ -159,6 +159,32 @@ class _FusedMarch(torch.autograd.Function):
         return grad_density, grad_k0, None, None, None
 
 
+@torch.no_grad()
+def fused_hit(rays_o, rays_d, cfg):
+    """bool [N]: rays with at least one in-box sample in occupied space (lib/dvgo.py:412-423), no sample
+    list materialised."""
+    rays_o, rays_d = rays_o.contiguous(), rays_d.contiguous()
+    for x, n in ((rays_o, 'rays_o'), (rays_d, 'rays_d')):
+        check_input(x, n); check_f32(x, n)
+    N, dev = rays_o.shape[0], rays_o.device
+    t_min = torch.empty(N, dtype=torch.float32, device=dev)
+    t_max = torch.empty_like(t_min)
+    n_steps = torch.empty(N, dtype=torch.int64, device=dev)
+    start = torch.empty((N, 3), dtype=torch.float32, device=dev)
+    dirs = torch.empty((N, 3), dtype=torch.float32, device=dev)
+    hit = torch.empty(N, dtype=torch.bool, device=dev)
+    mask = cfg.mask
+    with torch.cuda.device_of(rays_o):
+        st = stream_of(rays_o)
+        L.call('dvgo_sample_pts_prepare', ptr(rays_o), ptr(rays_d), ptr(cfg.xyz_min_t), ptr(cfg.xyz_max_t), _flt(cfg.near),
+               _flt(cfg.far), _flt(cfg.stepdist), _i64(N), ptr(t_min), ptr(t_max), ptr(n_steps), ptr(None), ptr(start),
+               ptr(dirs), st)
+        L.call('dvgo_march_hit', ptr(start), ptr(dirs), ptr(n_steps), _i64(N), cfg.xyz_min_h, cfg.xyz_max_h,
+               _flt(cfg.stepdist), ptr(mask), _int(mask.shape[0]), _int(mask.shape[1]), _int(mask.shape[2]), cfg.scale_h,
+               cfg.shift_h, ptr(hit), st)
+    return hit
+
+
 def fused_march(density, k0, rays_o, rays_d, cfg):
     """-> weights [M3], raw_alpha [M3], alphainv_last [N], k0 features [M3,C], ray_id, step_id [M3],
     off3 [N+1] (exclusive offsets of each ray's samples in the M3 arrays)."""

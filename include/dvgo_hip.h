@@ -201,6 +201,13 @@ int dvgo_march_density(const float* rays_start, const float* rays_dir,
                        dvgo_rec2_t* rec2, dvgo_rec3_t* rec3,
                        int32_t* n2, int32_t* n3, float* alphainv_last, void* stream);
 
+/* dvgo_march_hit: hit[r] = 1 iff ray r has an in-box sample whose nearest occupancy voxel is set -- the fused
+ *   form of DirectVoxGO.hit_coarse_geo (lib/dvgo.py:412-423), one wavefront per ray.  Host pointers as above. */
+int dvgo_march_hit(const float* rays_start, const float* rays_dir, const int64_t* n_steps, int64_t n_rays,
+                   const float* xyz_min, const float* xyz_max, float stepdist,
+                   const uint8_t* mask, int mX, int mY, int mZ,
+                   const float* xyz2ijk_scale, const float* xyz2ijk_shift, uint8_t* hit, void* stream);
+
 /* exclusive scan of int32 counts -> int64 offsets [n+1] (offsets[n] = total) */
 int dvgo_exclusive_scan_i32(const int32_t* counts, int64_t n, int64_t* offsets, void* stream);
 

@@ -90,6 +90,9 @@ def test_sample_ray_and_hit_coarse_geo(name, fine):
     assert np.array_equal(rid.cpu().numpy(), g['sample_ray_id'])
     assert np.array_equal(sid.cpu().numpy(), g['sample_step_id'])
     assert np.array_equal(m.hit_coarse_geo(rays_o=ro, rays_d=rd, **rk).cpu().numpy(), g['hit'])
+    m.fused = True                                         # fused hit kernel (one wavefront per ray), image-shaped input
+    hit = m.hit_coarse_geo(rays_o=ro.reshape(1, -1, 3), rays_d=rd.reshape(1, -1, 3), **rk)
+    assert hit.shape == (1, ro.shape[0]) and np.array_equal(hit[0].cpu().numpy(), g['hit'])
 
 
 def test_channel_first_layout_gives_same_result():

@@ -16,7 +16,8 @@ from directvoxgo_amd.scenes import pose_spherical, synthetic_scene
 ap = argparse.ArgumentParser()
 ap.add_argument('--world', type=int, default=256)
 ap.add_argument('--views', type=int, default=3)
-ap.add_argument('--hw', type=int, default=800)
+ap.add_argument("--hw", type=int, default=800)
+ap.add_argument("--chunk", type=int, default=8192)
 args = ap.parse_args()
 
 sc = synthetic_scene(world=args.world, n_rays=8, device='cuda')
@@ -32,7 +33,7 @@ rk = dict(near=2.0, far=6.0, bg=1, stepsize=0.5, inverse_y=False)
 render_viewpoints(m, poses[:1], [(H, W)], [K], False, rk)            # warm-up
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-rgbs, depths = render_viewpoints(m, poses, [(H, W)] * len(poses), [K] * len(poses), False, rk)
+rgbs, depths = render_viewpoints(m, poses, [(H, W)] * len(poses), [K] * len(poses), False, rk, chunk=args.chunk)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / len(poses)
 print(f'grid {args.world}^3 occupancy {sc["occupancy"]:.3f}: {dt * 1e3:.1f} ms per {H}x{W} view ({H * W / dt / 1e6:.2f} M rays/s), '
