@@ -56,8 +56,8 @@ def algorithmic_bytes(name, N, M_d, M2, M_k, C, n_grid):
         'dvgo_adam_upd': None,                                              # per call: 28 B / element (dense)
         # colour head (row N3): MFMA-bound, bytes listed for completeness (features / activations in and out)
         'dvgo_shade_fwd': M_k * (C * 4 + 8 + 12 + 2 * 512),
-        'dvgo_shade_bwd': M_k * (24 + 4 * 512 + C * 4),
-        'dvgo_shade_wgrad': M_k * (4 * 512 + C * 4 + 12),
+        'dvgo_shade_bwd': M_k * (24 + 32 + 512 + C * 4),
+        'dvgo_shade_wgrad': M_k * (3 * 512 + 16 + C * 4 + 12),
     }[name]
 
 

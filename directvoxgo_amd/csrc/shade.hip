@@ -214,8 +214,9 @@ shade_fwd_kernel(const float* __restrict__ feat, int C, int c_view0, int n_view,
 //                                                the B operands (same trick as the forward)
 //   gx  = W1[:, :32]^T G1                        MFMA, only the first 32 input features are produced
 //                                                (the feature-grid part; the view embedding needs no grad)
-// G1, G2 and gz are written out for the weight gradients (dW = G^T H, reductions over all samples,
-// done as split-K batched GEMMs by the caller); g_feat gets gz (diffuse) and gx.
+// G1 and gz are written out for the weight gradients (dvgo_shade_wgrad); G2 is NOT: it is three FMAs and a
+// mask bit away from gz, so the weight-gradient kernel rebuilds it (same expression, same bits) instead of
+// paying 512 B/sample of store here and 512 B/sample of load there.  g_feat gets gz (diffuse) and gx.
 // ----------------------------------------------------------------------------------
 template <int WIDTH>
 struct ShadeBwdLds {
@@ -230,8 +231,7 @@ __global__ void __launch_bounds__(SHADE_THREADS)
 shade_bwd_kernel(const float* __restrict__ g_rgb, const float* __restrict__ rgb,
                  const unsigned long long* __restrict__ masks, int64_t M, const float* __restrict__ W1, const float* __restrict__ W2,
                  const float* __restrict__ W3, int D_in, int C, int c_view0, int n_view,
-                 float* __restrict__ g_feat, float* __restrict__ G1, float* __restrict__ G2, float* __restrict__ gz_out,
-                 int experiment) {
+                 float* __restrict__ g_feat, float* __restrict__ G1, float* __restrict__ gz_out, int experiment) {
   constexpr int T = WIDTH / 32;
   __shared__ ShadeBwdLds<WIDTH> L;
   {
@@ -280,18 +280,10 @@ shade_bwd_kernel(const float* __restrict__ g_rgb, const float* __restrict__ rgb,
 #pragma unroll
     for (int t2 = 0; t2 < T; ++t2) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int f = 32 * t2 + 8 * q + 4 * h;
-        float o[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int r = 4 * q + e;
-          const float v = fmaf(L.w3p[2][h][t2 * 16 + r], gz[2],
-                               fmaf(L.w3p[1][h][t2 * 16 + r], gz[1], L.w3p[0][h][t2 * 16 + r] * gz[0]));
-          o[e] = ((m2 >> (16 * t2 + r)) & 1ull) ? v : 0.0f;   // gz == 0 on rows past M, so o == 0 there
-          g2[t2][r] = o[e];
-        }
-        if (valid && !(experiment & 1)) *reinterpret_cast<float4*>(G2 + row * WIDTH + f) = make_float4(o[0], o[1], o[2], o[3]);
+      for (int r = 0; r < 16; ++r) {
+        const float v = fmaf(L.w3p[2][h][t2 * 16 + r], gz[2],
+                             fmaf(L.w3p[1][h][t2 * 16 + r], gz[1], L.w3p[0][h][t2 * 16 + r] * gz[0]));
+        g2[t2][r] = ((m2 >> (16 * t2 + r)) & 1ull) ? v : 0.0f;   // gz == 0 on rows past M, so G2 == 0 there
       }
     }
     f32x16 gx;
@@ -336,6 +328,8 @@ shade_bwd_kernel(const float* __restrict__ g_rgb, const float* __restrict__ rgb,
 
 // ----------------------------------------------------------------------------------
 // Backward, weight-gradient part:  dW2 = G2^T H1,  dW1 = G1^T X,  dW3 = gz^T H2,  db = column sums.
+// G2[row][f] = bit(mask2[row], f) ? W3[:, f] . gz[row] : 0 is rebuilt per operand from gz and the layer-2 sign
+// bits (3 FMAs, the expression of shade_bwd_kernel), so only G1, H1, H2 are streamed.
 // All operands are row-major [M, features], and a contraction over ROWS wants exactly that:
 //   A[i = out feature][k = row]  : lane (i, h) reads G[row = 2s + h][f0 + i]
 //   B[k = row][j = in feature]   : lane (j, h) reads H[row = 2s + h][f0' + j]
@@ -351,9 +345,10 @@ shade_bwd_kernel(const float* __restrict__ g_rgb, const float* __restrict__ rgb,
 template <int WIDTH>
 struct ShadeWgradLds {
   // single-buffered 32-row tiles (74 KB): two workgroups share a CU and cover each other's load phase
-  float g1[1][32][WIDTH], g2[1][32][WIDTH], h1[1][32][WIDTH], h2[1][32][WIDTH];
+  float g1[1][32][WIDTH], h1[1][32][WIDTH], h2[1][32][WIDTH];
   float x[1][32][64];
   float gz[1][32][4];
+  unsigned int m2[1][32][2][2];     // layer-2 sign bits [row][lane half of the forward][32-bit half]
 };
 
 typedef const __attribute__((address_space(1))) void* dvgo_gptr_t;
@@ -361,8 +356,8 @@ typedef __attribute__((address_space(3))) void* dvgo_lptr_t;
 
 template <int WIDTH>
 __global__ void __launch_bounds__(256)
-shade_wgrad_kernel(const float* __restrict__ G1, const float* __restrict__ G2, const float* __restrict__ gz,
-                   const float* __restrict__ H1, const float* __restrict__ H2, const float* __restrict__ feat, int C,
+shade_wgrad_kernel(const float* __restrict__ G1, const float* __restrict__ gz, const unsigned int* __restrict__ masks,
+                   const float* __restrict__ W3, const float* __restrict__ H1, const float* __restrict__ H2, const float* __restrict__ feat, int C,
                    int c_view0, int n_view, const float* __restrict__ emb, int E, const int64_t* __restrict__ ray_id,
                    int64_t M, float* __restrict__ part /* [gridDim][WIDTH*WIDTH + WIDTH*64 + 32*WIDTH + 3*WIDTH] */) {
   constexpr int T = WIDTH / 32;
@@ -381,6 +376,10 @@ shade_wgrad_kernel(const float* __restrict__ G1, const float* __restrict__ G2, c
 #pragma unroll
   for (int kk = 0; kk < 8; ++kk) vW1[kk] = 0.0f;
   float sb1 = 0.0f, sb2 = 0.0f, gz_acc = 0.0f;   // bias gradients: column sums of the A operands / of gz
+  // this lane's out feature f = 32w + j of layer 2: its W3 column, and where its sign bit lives in the forward's
+  // accumulator-order masks (f = 32t + (r&3) + 8(r>>2) + 4h'  ->  word h', bit 16t + r)
+  const float w30 = W3[32 * w + j], w31 = W3[WIDTH + 32 * w + j], w32 = W3[2 * WIDTH + 32 * w + j];
+  const int m_half = (j >> 2) & 1, m_word = w >> 1, m_bit = 16 * (w & 1) + (j & 3) + 4 * (j >> 3);
   const int d_in = n_view + E;
   const int64_t n_tiles = (M + 31) / 32;
 
@@ -390,6 +389,7 @@ shade_wgrad_kernel(const float* __restrict__ G1, const float* __restrict__ G2, c
   // clamped row and masked at operand read.
   // The small assembled X tile and gz travel through registers.
   float px[8], pgz;
+  unsigned int pm2;
 #define SHADE_WGRAD_DMA(TILE, BUF)                                                                              \
   {                                                                                                             \
     const int64_t r0_ = (TILE) * 32;                                                                            \
@@ -398,7 +398,6 @@ shade_wgrad_kernel(const float* __restrict__ G1, const float* __restrict__ G2, c
       const int64_t row = r0_ + rl + h;                                                                         \
       const int64_t off = (row < M ? row : M - 1) * WIDTH + 4 * j;                                              \
       __builtin_amdgcn_global_load_lds((dvgo_gptr_t)(G1 + off), (dvgo_lptr_t)&L.g1[BUF][rl][0], 16, 0, 0);     \
-      __builtin_amdgcn_global_load_lds((dvgo_gptr_t)(G2 + off), (dvgo_lptr_t)&L.g2[BUF][rl][0], 16, 0, 0);     \
       __builtin_amdgcn_global_load_lds((dvgo_gptr_t)(H1 + off), (dvgo_lptr_t)&L.h1[BUF][rl][0], 16, 0, 0);     \
       __builtin_amdgcn_global_load_lds((dvgo_gptr_t)(H2 + off), (dvgo_lptr_t)&L.h2[BUF][rl][0], 16, 0, 0);     \
     }                                                                                                           \
@@ -419,6 +418,8 @@ shade_wgrad_kernel(const float* __restrict__ G1, const float* __restrict__ G2, c
       const int64_t rc = row < M ? row : M - 1;                                                                 \
       const int c = (tid & 3) < 3 ? (tid & 3) : 0;                                                              \
       pgz = ((tid & 3) < 3 && row < M) ? gz[rc * 3 + c] : 0.0f;                                                 \
+      /* masks [M][2 layers][2 halves] u64 = [M][8] u32: layer 2 = words 4..7 (values past M are never used: gz == 0) */ \
+      pm2 = masks[rc * 8 + 4 + (tid & 3)];                                                                      \
     }                                                                                                           \
   }
 
@@ -427,14 +428,19 @@ shade_wgrad_kernel(const float* __restrict__ G1, const float* __restrict__ G2, c
     SHADE_WGRAD_DMA(tile, 0);
 #pragma unroll
     for (int i = 0; i < 8; ++i) L.x[buf][tid >> 3][(tid & 7) + 8 * i] = px[i];
-    if (tid < 128) L.gz[buf][tid >> 2][tid & 3] = pgz;
+    if (tid < 128) {
+      L.gz[buf][tid >> 2][tid & 3] = pgz;
+      (&L.m2[buf][tid >> 2][0][0])[tid & 3] = pm2;
+    }
     __syncthreads();      // DMA of this tile has landed (vmcnt(0) precedes the barrier), X / gz committed
     const int64_t r0 = tile * 32;
 #pragma unroll 4
     for (int s = 0; s < 16; ++s) {
       const int row = 2 * s + h;
       const float rm = (r0 + row < M) ? 1.0f : 0.0f;
-      const float a2 = L.g2[buf][row][32 * w + j] * rm;
+      const float4 gzr = *reinterpret_cast<const float4*>(&L.gz[buf][row][0]);      // broadcast; 0 on rows past M
+      const float g2v = fmaf(w32, gzr.z, fmaf(w31, gzr.y, w30 * gzr.x));
+      const float a2 = ((L.m2[buf][row][m_half][m_word] >> m_bit) & 1u) ? g2v : 0.0f;
       const float a1 = L.g1[buf][row][32 * w + j] * rm;
       sb2 += a2; sb1 += a1;
       if (j < 3) gz_acc += L.gz[buf][row][j];
@@ -445,8 +451,7 @@ shade_wgrad_kernel(const float* __restrict__ G1, const float* __restrict__ G2, c
 #pragma unroll
       for (int kk = 0; kk < 8; ++kk) vW1[kk] = fmaf(a1, L.x[buf][row][32 + kk], vW1[kk]);   // broadcast reads; zero past d_in
       const float hv = L.h2[buf][row][32 * w + j];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) vW3[c] = fmaf(L.gz[buf][row][c], hv, vW3[c]);           // gz == 0 on rows past M
+      vW3[0] = fmaf(gzr.x, hv, vW3[0]); vW3[1] = fmaf(gzr.y, hv, vW3[1]); vW3[2] = fmaf(gzr.z, hv, vW3[2]);
     }
     __syncthreads();      // every wave is done with the tile before the next DMA overwrites it
   }
@@ -519,10 +524,10 @@ int dvgo_shade_experiment(int flags) { g_shade_experiment = flags; return 0; }
 
 int dvgo_shade_bwd(const float* g_rgb, const float* rgb, const uint64_t* masks, int64_t M,
                    const float* W1, const float* W2, const float* W3, int width, int d_in, int C, int diffuse,
-                   float* g_feat, float* G1, float* G2, float* gz, void* stream) {
+                   float* g_feat, float* G1, float* gz, void* stream) {
   if (M < 0 || C <= 0) return DVGO_EINVAL;
   if (M == 0) return 0;
-  if (!g_rgb || !rgb || !masks || !W1 || !W2 || !W3 || !g_feat || !G1 || !G2 || !gz) return DVGO_EINVAL;
+  if (!g_rgb || !rgb || !masks || !W1 || !W2 || !W3 || !g_feat || !G1 || !gz) return DVGO_EINVAL;
   const int c_view0 = diffuse ? 3 : 0;
   const int n_view = C - c_view0;
   if (width != 128 || n_view < 0 || n_view > 32 || d_in < n_view) return DVGO_ERANGE;
@@ -531,24 +536,24 @@ int dvgo_shade_bwd(const float* g_rgb, const float* rgb, const uint64_t* masks, 
   int blocks = (int)((n_tiles + SHADE_WAVES - 1) / SHADE_WAVES < 256 ? (n_tiles + SHADE_WAVES - 1) / SHADE_WAVES : 256);
   if (diffuse)
     shade_bwd_kernel<128, true><<<blocks, SHADE_THREADS, 0, s>>>(g_rgb, rgb, (const unsigned long long*)masks, M, W1, W2, W3, d_in, C, c_view0,
-                                                                 n_view, g_feat, G1, G2, gz, g_shade_experiment);
+                                                                 n_view, g_feat, G1, gz, g_shade_experiment);
   else
     shade_bwd_kernel<128, false><<<blocks, SHADE_THREADS, 0, s>>>(g_rgb, rgb, (const unsigned long long*)masks, M, W1, W2, W3, d_in, C, c_view0,
-                                                                  n_view, g_feat, G1, G2, gz, g_shade_experiment);
+                                                                  n_view, g_feat, G1, gz, g_shade_experiment);
   DVGO_LAUNCH_CHECK();
   return 0;
 }
 
-int dvgo_shade_wgrad(const float* G1, const float* G2, const float* gz, const float* H1, const float* H2,
-                     const float* feat, int C, const float* emb, int E, const int64_t* ray_id, int64_t M, int width,
+int dvgo_shade_wgrad(const float* G1, const float* gz, const uint64_t* masks, const float* W3, const float* H1,
+                     const float* H2, const float* feat, int C, const float* emb, int E, const int64_t* ray_id, int64_t M, int width,
                      int diffuse, int n_parts, float* part, void* stream) {
   if (M < 0 || n_parts <= 0 || C <= 0 || E < 0) return DVGO_EINVAL;
-  if (!G1 || !G2 || !gz || !H1 || !H2 || !feat || !emb || !ray_id || !part) return DVGO_EINVAL;
+  if (!G1 || !gz || !masks || !W3 || !H1 || !H2 || !feat || !emb || !ray_id || !part) return DVGO_EINVAL;
   const int c_view0 = diffuse ? 3 : 0;
   const int n_view = C - c_view0;
   if (width != 128 || n_view < 0 || n_view + E > 64) return DVGO_ERANGE;
-  shade_wgrad_kernel<128><<<n_parts, 256, 0, (hipStream_t)stream>>>(G1, G2, gz, H1, H2, feat, C, c_view0, n_view, emb, E,
-                                                                    ray_id, M, part);
+  shade_wgrad_kernel<128><<<n_parts, 256, 0, (hipStream_t)stream>>>(
+      G1, gz, (const unsigned int*)masks, W3, H1, H2, feat, C, c_view0, n_view, emb, E, ray_id, M, part);
   DVGO_LAUNCH_CHECK();
   return 0;
 }

@@ -99,19 +99,18 @@ class _Shade(torch.autograd.Function):
         width, d_in = W1.shape
         g_feat = torch.empty_like(feat)
         G1 = torch.empty_like(H1)
-        G2 = torch.empty_like(H2)
         gz = torch.empty_like(rgb)
         with torch.cuda.device_of(feat):
             L.call('dvgo_shade_bwd', ptr(g_rgb.contiguous()), ptr(rgb), ptr(masks), _i64(M), ptr(W1.contiguous()),
                    ptr(W2.contiguous()), ptr(W3.contiguous()), _int(width), _int(d_in), _int(C), _int(1 if diffuse else 0),
-                   ptr(g_feat), ptr(G1), ptr(G2), ptr(gz), stream_of(feat))
+                   ptr(g_feat), ptr(G1), ptr(gz), stream_of(feat))
 
         def wgrad():
             n_parts = max(1, min(N_PARTS, (M + 511) // 512))      # >= 16 row tiles per workgroup on small batches
             psize = width * width + width * 64 + 32 * width + 3 * width
             part = torch.empty((n_parts, psize), dtype=torch.float32, device=feat.device)
             with torch.cuda.device_of(feat):
-                L.call('dvgo_shade_wgrad', ptr(G1), ptr(G2), ptr(gz), ptr(H1), ptr(H2), ptr(feat), _int(C), ptr(emb),
+                L.call('dvgo_shade_wgrad', ptr(G1), ptr(gz), ptr(masks), ptr(W3.contiguous()), ptr(H1), ptr(H2), ptr(feat), _int(C), ptr(emb),
                        _int(emb.shape[1]), ptr(ray_id), _i64(M), _int(width), _int(1 if diffuse else 0), _int(n_parts),
                        ptr(part), stream_of(feat))
             tot = part.sum(0)

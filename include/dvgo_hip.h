@@ -277,20 +277,22 @@ int dvgo_shade_fwd(const float* feat, int C, const float* emb, int E, const int6
                    float* rgb, float* H1, float* H2, uint64_t* masks, void* stream);
 
 /* Data-gradient part of the colour-head backward.  Inputs: g_rgb, rgb [M,3]; the saved activations
- * sign-bit masks written by dvgo_shade_fwd.  Outputs: gz [M,3] (= g_rgb * sigmoid'), G2 = relu'(H2) * (W3^T gz) and
- * G1 = relu'(H1) * (W2^T G2) as [M,width] (operands of dvgo_shade_wgrad), and g_feat [M,C] fully written:
+ * sign-bit masks written by dvgo_shade_fwd.  Outputs: gz [M,3] (= g_rgb * sigmoid'),
+ * G1 = relu'(H1) * (W2^T G2) as [M,width] where G2 = relu'(H2) * (W3^T gz) stays in registers (dvgo_shade_wgrad
+ * rebuilds it from gz and the masks rather than streaming 512 B/sample), and g_feat [M,C] fully written:
  * channels [0,3) = gz when diffuse, channels [c0, C) = (W1^T G1)[:C-c0]. */
 int dvgo_shade_bwd(const float* g_rgb, const float* rgb, const uint64_t* masks, int64_t M,
                    const float* W1, const float* W2, const float* W3, int width, int d_in, int C, int diffuse,
-                   float* g_feat, float* G1, float* G2, float* gz, void* stream);
+                   float* g_feat, float* G1, float* gz, void* stream);
 
-/* Weight-gradient part: dW2 = G2^T H1, dW1 = G1^T X (X = the layer-1 input, re-assembled from feat / emb /
+/* Weight-gradient part (G1, gz from dvgo_shade_bwd; masks, H1, H2 from dvgo_shade_fwd; W3 as given to both):
+ * dW2 = G2^T H1, dW1 = G1^T X (X = the layer-1 input, re-assembled from feat / emb /
  * ray_id exactly as in dvgo_shade_fwd), dW3 = gz^T H2 and the three bias gradients (column sums); fp32 MFMA
  * with both operands read row-major straight from memory.  Every one of the n_parts workgroups writes its
  * partial sums to part[p] = { dW2 [width][width], dW1 [width][64], dW3 [32][width] (rows 0..2 valid),
  * db1 [width], db2 [width], db3 [width] (first 3 valid) } floats; the caller sums over p. */
-int dvgo_shade_wgrad(const float* G1, const float* G2, const float* gz, const float* H1, const float* H2,
-                     const float* feat, int C, const float* emb, int E, const int64_t* ray_id, int64_t M,
+int dvgo_shade_wgrad(const float* G1, const float* gz, const uint64_t* masks, const float* W3,
+                     const float* H1, const float* H2, const float* feat, int C, const float* emb, int E, const int64_t* ray_id, int64_t M,
                      int width, int diffuse, int n_parts, float* part, void* stream);
 
 /* ---------------------------------------------------------------------------------
