@@ -346,7 +346,7 @@ template <int WIDTH>
 struct ShadeWgradLds {
   // single-buffered 32-row tiles (74 KB): two workgroups share a CU and cover each other's load phase
   float g1[1][32][WIDTH], h1[1][32][WIDTH], h2[1][32][WIDTH];
-  float x[1][32][64];
+  float x[1][32][40];
   float gz[1][32][4];
   unsigned int m2[1][32][2][2];     // layer-2 sign bits [row][lane half of the forward][32-bit half]
 };
@@ -388,11 +388,40 @@ shade_wgrad_kernel(const float* __restrict__ G1, const float* __restrict__ gz, c
   // tile at a time; the second workgroup resident on the CU computes meanwhile.  Rows past M are read from a
   // clamped row and masked at operand read.
   // The small assembled X tile and gz travel through registers.
-  float px[8], pgz;
+  float px[5], pgz;
   unsigned int pm2;
+  bool pvalid, pgvalid;
+  int64_t ray_nx;
+  {
+    const int64_t row = (int64_t)blockIdx.x * 32 + (tid >> 3);
+    ray_nx = ray_id[row < M ? row : M - 1];
+  }
 #define SHADE_WGRAD_DMA(TILE, BUF)                                                                              \
   {                                                                                                             \
     const int64_t r0_ = (TILE) * 32;                                                                            \
+    {                                                                                                           \
+      const int64_t row = r0_ + (tid >> 3);                                                                     \
+      const int64_t rc = row < M ? row : M - 1;                                                                 \
+      const float* fr = feat + rc * C + c_view0;                                                                \
+      const float* er = emb + ray_nx * E - n_view;      /* ray_nx was fetched one tile earlier */               \
+      _Pragma("unroll") for (int i = 0; i < 5; ++i) {   /* columns 0..39; d_in <= 40 */                         \
+        const int k = (tid & 7) + 8 * i;                                                                        \
+        const int kc = k < d_in ? k : d_in - 1;                                                                 \
+        px[i] = *((kc < n_view) ? fr + kc : er + kc);                                                           \
+      }                                                                                                         \
+      pvalid = row < M;                                                                                         \
+      const int64_t row2 = r0_ + (int64_t)gridDim.x * 32 + (tid >> 3);                                          \
+      ray_nx = ray_id[row2 < M ? row2 : M - 1];         /* for the next tile of this workgroup */               \
+    }                                                                                                           \
+    {                                                                                                           \
+      const int64_t row = r0_ + ((tid & 127) >> 2);                                                             \
+      const int64_t rc = row < M ? row : M - 1;                                                                 \
+      pgz = gz[rc * 3 + ((tid & 3) < 3 ? (tid & 3) : 0)];                                                       \
+      pgvalid = (tid & 3) < 3 && row < M;                                                                       \
+      /* masks [M][2 layers][2 halves] u64 = [M][8] u32: layer 2 = words 4..7 (values past M are never used: gz == 0) */ \
+      pm2 = masks[rc * 8 + 4 + (tid & 3)];                                                                      \
+    }                                                                                                           \
+    /* the bulk DMA goes last: the (in-order) wait for ray_nx above then costs nothing */                       \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                             \
       const int rl = 8 * w + 2 * i;                     /* this wave instruction covers rows rl, rl + 1 */      \
       const int64_t row = r0_ + rl + h;                                                                         \
@@ -401,38 +430,21 @@ shade_wgrad_kernel(const float* __restrict__ G1, const float* __restrict__ gz, c
       __builtin_amdgcn_global_load_lds((dvgo_gptr_t)(H1 + off), (dvgo_lptr_t)&L.h1[BUF][rl][0], 16, 0, 0);     \
       __builtin_amdgcn_global_load_lds((dvgo_gptr_t)(H2 + off), (dvgo_lptr_t)&L.h2[BUF][rl][0], 16, 0, 0);     \
     }                                                                                                           \
-    {                                                                                                           \
-      const int64_t row = r0_ + (tid >> 3);                                                                     \
-      const int64_t rc = row < M ? row : M - 1;                                                                 \
-      const float* fr = feat + rc * C + c_view0;                                                                \
-      const float* er = emb + ray_id[rc] * E - n_view;                                                          \
-      _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                           \
-        const int k = (tid & 7) + 8 * i;                                                                        \
-        const int kc = k < d_in ? k : d_in - 1;                                                                 \
-        const float v = (kc < n_view) ? fr[kc] : er[kc];                                                        \
-        px[i] = (k < d_in && row < M) ? v : 0.0f;                                                               \
-      }                                                                                                         \
-    }                                                                                                           \
-    {                                                                                                           \
-      const int64_t row = r0_ + ((tid & 127) >> 2);                                                             \
-      const int64_t rc = row < M ? row : M - 1;                                                                 \
-      const int c = (tid & 3) < 3 ? (tid & 3) : 0;                                                              \
-      pgz = ((tid & 3) < 3 && row < M) ? gz[rc * 3 + c] : 0.0f;                                                 \
-      /* masks [M][2 layers][2 halves] u64 = [M][8] u32: layer 2 = words 4..7 (values past M are never used: gz == 0) */ \
-      pm2 = masks[rc * 8 + 4 + (tid & 3)];                                                                      \
-    }                                                                                                           \
   }
 
   constexpr int buf = 0;
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     SHADE_WGRAD_DMA(tile, 0);
+    // the small loads above are unconditional and all in flight together (one round trip); masked here
+    asm volatile("" : "+v"(px[0]), "+v"(px[1]), "+v"(px[2]), "+v"(px[3]), "+v"(px[4]), "+v"(pgz), "+v"(pm2));
 #pragma unroll
-    for (int i = 0; i < 8; ++i) L.x[buf][tid >> 3][(tid & 7) + 8 * i] = px[i];
+    for (int i = 0; i < 5; ++i) L.x[buf][tid >> 3][(tid & 7) + 8 * i] = (pvalid && (tid & 7) + 8 * i < d_in) ? px[i] : 0.0f;
     if (tid < 128) {
-      L.gz[buf][tid >> 2][tid & 3] = pgz;
+      L.gz[buf][tid >> 2][tid & 3] = pgvalid ? pgz : 0.0f;
       (&L.m2[buf][tid >> 2][0][0])[tid & 3] = pm2;
     }
-    __syncthreads();      // DMA of this tile has landed (vmcnt(0) precedes the barrier), X / gz committed
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's share of the DMA has landed (the compiler does not
+    __syncthreads();                      // track LDS-DMA completion for us); X / gz / masks committed
     const int64_t r0 = tile * 32;
 #pragma unroll 4
     for (int s = 0; s < 16; ++s) {
@@ -443,13 +455,16 @@ shade_wgrad_kernel(const float* __restrict__ G1, const float* __restrict__ gz, c
       const float a2 = ((L.m2[buf][row][m_half][m_word] >> m_bit) & 1u) ? g2v : 0.0f;
       const float a1 = L.g1[buf][row][32 * w + j] * rm;
       sb2 += a2; sb1 += a1;
-      if (j < 3) gz_acc += L.gz[buf][row][j];
+      gz_acc += L.gz[buf][row][j & 3];                    // lanes j < 3 are the ones read out
 #pragma unroll
       for (int t = 0; t < T; ++t)
         aW2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, L.h1[buf][row][32 * t + j], aW2[t], 0, 0, 0);
       aW1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, L.x[buf][row][j], aW1, 0, 0, 0);
-#pragma unroll
-      for (int kk = 0; kk < 8; ++kk) vW1[kk] = fmaf(a1, L.x[buf][row][32 + kk], vW1[kk]);   // broadcast reads; zero past d_in
+      const float4 xa = *reinterpret_cast<const float4*>(&L.x[buf][row][32]);       // broadcast; zero past d_in
+      const float4 xb = *reinterpret_cast<const float4*>(&L.x[buf][row][36]);
+      vW1[0] = fmaf(a1, xa.x, vW1[0]); vW1[1] = fmaf(a1, xa.y, vW1[1]); vW1[2] = fmaf(a1, xa.z, vW1[2]);
+      vW1[3] = fmaf(a1, xa.w, vW1[3]); vW1[4] = fmaf(a1, xb.x, vW1[4]); vW1[5] = fmaf(a1, xb.y, vW1[5]);
+      vW1[6] = fmaf(a1, xb.z, vW1[6]); vW1[7] = fmaf(a1, xb.w, vW1[7]);
       const float hv = L.h2[buf][row][32 * w + j];
       vW3[0] = fmaf(gzr.x, hv, vW3[0]); vW3[1] = fmaf(gzr.y, hv, vW3[1]); vW3[2] = fmaf(gzr.z, hv, vW3[2]);
     }
@@ -551,7 +566,7 @@ int dvgo_shade_wgrad(const float* G1, const float* gz, const uint64_t* masks, co
   if (!G1 || !gz || !masks || !W3 || !H1 || !H2 || !feat || !emb || !ray_id || !part) return DVGO_EINVAL;
   const int c_view0 = diffuse ? 3 : 0;
   const int n_view = C - c_view0;
-  if (width != 128 || n_view < 0 || n_view + E > 64) return DVGO_ERANGE;
+  if (width != 128 || n_view < 0 || n_view + E > 40) return DVGO_ERANGE;
   shade_wgrad_kernel<128><<<n_parts, 256, 0, (hipStream_t)stream>>>(
       G1, gz, (const unsigned int*)masks, W3, H1, H2, feat, C, c_view0, n_view, emb, E, ray_id, M, part);
   DVGO_LAUNCH_CHECK();
