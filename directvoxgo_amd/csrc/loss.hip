@@ -55,9 +55,9 @@ loss_samples_kernel(const float* __restrict__ raw_rgb, const float* __restrict__
                     const int64_t* __restrict__ ray_id, const float* __restrict__ target, int64_t M,
                     float inv_n_global, float w_per, float* __restrict__ g_raw_rgb, float* __restrict__ loss_out) {
   __shared__ float red[4];
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   float l = 0.0f;
-  if (i < M) {
+  // grid-stride: one same-address atomic per workgroup is the cost that matters here, so few, long-lived workgroups
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = ray_id[i];
     const float w = weights[i];
     float se = 0.0f;
@@ -67,7 +67,7 @@ loss_samples_kernel(const float* __restrict__ raw_rgb, const float* __restrict__
       se = fmaf(d, d, se);
       g_raw_rgb[3 * i + c] = 2.0f * w_per * w * d * inv_n_global;
     }
-    l = w_per * w * se * inv_n_global;
+    l += w_per * w * se * inv_n_global;
   }
   const float t = block_sum_256(l, red);
   if (threadIdx.x == 0) atomicAdd(loss_out, t);
@@ -137,7 +137,8 @@ int dvgo_loss_fwd_bwd(const float* rgb_marched, const float* alphainv_last, cons
   }
   if (M > 0 && w_per > 0.0f) {
     if (!raw_rgb || !weights || !ray_id || !g_raw_rgb) return DVGO_EINVAL;
-    loss_samples_kernel<<<dvgo_blocks(M, 256), 256, 0, s>>>(raw_rgb, weights, ray_id, target, M, inv, w_per, g_raw_rgb,
+    const int64_t nb = dvgo_blocks(M, 256);
+    loss_samples_kernel<<<(int)(nb < 1024 ? nb : 1024), 256, 0, s>>>(raw_rgb, weights, ray_id, target, M, inv, w_per, g_raw_rgb,
                                                             loss_out);
     DVGO_LAUNCH_CHECK();
   }
