@@ -370,15 +370,22 @@ march_feat_bwd_kernel(const float* __restrict__ grad_feat, const int64_t* __rest
 //      gradient row from LDS, accumulate in a register, emit ONE global atomic per (corner, channel).
 // A corner that cannot be placed within the probe bound falls back to direct global atomics.
 // ----------------------------------------------------------------------------------
-template <int C>
+// EXTRA: one more per-sample scalar (grad_extra[i], the density gradient of the kept samples) travels as channel C
+// of the same row, so that with 64-byte rows (RS = 16 floats) the density scatter costs no atomic request of its
+// own: float atomics are bound by 64-B requests (~19.7 G/s), and a 48-B row at a 48-B stride straddles two
+// requests half of the time (0.465 -> 0.34 ms from the alignment alone on the roofline case).
+template <int C, bool EXTRA>
 __global__ void __launch_bounds__(DVGO_BLOCK)
-march_feat_bwd_dedup_kernel(const float* __restrict__ grad_feat, const int64_t* __restrict__ ray_id,
+march_feat_bwd_dedup_kernel(const float* __restrict__ grad_feat, const float* __restrict__ grad_extra,
+                            const int64_t* __restrict__ ray_id,
                             const int64_t* __restrict__ step_id, int64_t M3,
                             const float* __restrict__ rays_start, const float* __restrict__ rays_dir,
-                            MarchParams P, float* __restrict__ grad_k0) {
+                            MarchParams P, float* __restrict__ grad_k0, int RS) {
   constexpr int H = 256;        // table slots per wave (>= corner references per pass)
   constexpr int SPP = 32;       // samples per pass
-  constexpr int RPI = 64 / C;   // corner rows per atomic wave-instruction
+  constexpr int CE = C + (EXTRA ? 1 : 0);       // channels scattered per corner row
+  constexpr int GS = EXTRA ? (C + 4) : C;       // LDS row stride (keeps the float4 stores aligned)
+  constexpr int RPI = 64 / CE;  // corner rows per atomic wave-instruction
   struct WaveLds {
     int keys[H];
     int cnts[H];
@@ -386,7 +393,7 @@ march_feat_bwd_dedup_kernel(const float* __restrict__ grad_feat, const int64_t* 
     int list[H];
     float ref_w[H];
     int ref_s[H];
-    float g[SPP][C];
+    float g[SPP][GS];
   };
   __shared__ __attribute__((aligned(16))) WaveLds s_lds[4];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -397,7 +404,7 @@ march_feat_bwd_dedup_kernel(const float* __restrict__ grad_feat, const int64_t* 
   const int64_t n_pass = (M3 + SPP - 1) / SPP;
   const int64_t gwave = (int64_t)blockIdx.x * 4 + wave, nwaves = (int64_t)gridDim.x * 4;
   const int YZ = P.Y * P.Z;
-  const int rsub = lane / C, ch = lane - rsub * C;
+  const int rsub = lane / CE, ch = lane - rsub * CE;
   for (int64_t pass = gwave; pass < n_pass; pass += nwaves) {
     const int sl = lane >> 1, half = lane & 1;
     const int64_t i = pass * SPP + sl;
@@ -414,10 +421,12 @@ march_feat_bwd_dedup_kernel(const float* __restrict__ grad_feat, const int64_t* 
       float4 gv[C / 4];
 #pragma unroll
       for (int c = 0; c < C / 4; ++c) gv[c] = gp[c];
+      const float ge = EXTRA ? grad_extra[i] : 0.0f;
       if (half == 0) {
         float4* dst = reinterpret_cast<float4*>(&L.g[sl][0]);
 #pragma unroll
         for (int c = 0; c < C / 4; ++c) dst[c] = gv[c];
+        if (EXTRA) L.g[sl][C] = ge;
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -438,10 +447,11 @@ march_feat_bwd_dedup_kernel(const float* __restrict__ grad_feat, const int64_t* 
           tick[q] = atomicAdd(&L.cnts[sidx], 1);
           wq[q] = w;
         } else {
-          float* dst = grad_k0 + (int64_t)key * C;
+          float* dst = grad_k0 + (int64_t)key * RS;
           const float* gs = reinterpret_cast<const float*>(gv);
 #pragma unroll
           for (int c = 0; c < C; ++c) atomicAdd(dst + c, w * gs[c]);
+          if (EXTRA) atomicAdd(dst + C, w * ge);
         }
       }
     }
@@ -486,7 +496,7 @@ march_feat_bwd_dedup_kernel(const float* __restrict__ grad_feat, const int64_t* 
         const int beg = L.offs[s], n = L.cnts[s];
         float acc = 0.0f;
         for (int t = 0; t < n; ++t) acc = fmaf(L.ref_w[beg + t], L.g[L.ref_s[beg + t]][ch], acc);
-        atomicAdd(grad_k0 + (int64_t)key * C + ch, acc);
+        atomicAdd(grad_k0 + (int64_t)key * RS + ch, acc);
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -510,7 +520,9 @@ march_density_bwd_kernel(const dvgo_rec2_t* __restrict__ rec2, const int32_t* __
                          const float* __restrict__ rays_start, const float* __restrict__ rays_dir,
                          MarchParams P, const float* __restrict__ alphainv_last,
                          const float* __restrict__ grad_weights, const float* __restrict__ grad_last,
-                         float* __restrict__ grad_density) {
+                         float* __restrict__ grad_density, int64_t gstride /* elements between voxels */,
+                         float* __restrict__ grad_kept /* [M3] or null: kept samples hand their gradient to the
+                                                          feature scatter instead of scattering it here */) {
   constexpr int H = 512;
   __shared__ int s_keys[DEDUP ? 4 : 1][DEDUP ? H : 1];
   __shared__ float s_vals[DEDUP ? 4 : 1][DEDUP ? H : 1];
@@ -563,7 +575,8 @@ march_density_bwd_kernel(const dvgo_rec2_t* __restrict__ rec2, const int32_t* __
       const float dist = march_dist(P.stepdist, step);
       const float px = fmaf(dx, dist, sx), py = fmaf(dy, dist, sy), pz = fmaf(dz, dist, sz);
       const TriSetup t = dvgo_tri_setup(px, py, pz, P.mnx, P.mny, P.mnz, P.mxx, P.mxy, P.mxz, P.X, P.Y, P.Z);
-      if (g_d != 0.0f) {
+      if (grad_kept != nullptr && flag) grad_kept[o3 + rank] = g_d;
+      else if (g_d != 0.0f) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
           if (!dvgo_tri_inb(t, c, P.X, P.Y, P.Z)) continue;
@@ -580,9 +593,9 @@ march_density_bwd_kernel(const dvgo_rec2_t* __restrict__ rec2, const int32_t* __
               sidx = (sidx + 1) & (H - 1);
             }
             if (placed) atomicAdd(&vals[sidx], v);
-            else atomicAdd(grad_density + off, v);
+            else atomicAdd(grad_density + off * gstride, v);
           } else {
-            atomicAdd(grad_density + off, v);
+            atomicAdd(grad_density + off * gstride, v);
           }
         }
       }
@@ -594,7 +607,7 @@ march_density_bwd_kernel(const dvgo_rec2_t* __restrict__ rec2, const int32_t* __
         const int s = it * 64 + lane;
         const int k = keys[s];
         if (k != -1) {
-          atomicAdd(grad_density + k, vals[s]);
+          atomicAdd(grad_density + k * gstride, vals[s]);
           keys[s] = -1;
           vals[s] = 0.0f;
         }
@@ -729,8 +742,8 @@ int dvgo_march_composite_bwd(const float* grad_rgb_marched, const float* weights
   return 0;
 }
 
-int dvgo_march_feat_bwd(const float* grad_feat, const int64_t* ray_id, const int64_t* step_id, int64_t M3,
-                        const float* rays_start, const float* rays_dir, float stepdist,
+int dvgo_march_feat_bwd(const float* grad_feat, const float* grad_extra, const int64_t* ray_id, const int64_t* step_id,
+                        int64_t M3, const float* rays_start, const float* rays_dir, float stepdist,
                         const float* xyz_min, const float* xyz_max, int C, int X, int Y, int Z,
                         int64_t sC, int64_t sX, int64_t sY, int64_t sZ, float* grad_k0, void* stream) {
   if (M3 < 0 || C < 0 || X <= 0 || Y <= 0 || Z <= 0) return DVGO_EINVAL;
@@ -741,19 +754,56 @@ int dvgo_march_feat_bwd(const float* grad_feat, const int64_t* ray_id, const int
   const MarchParams P = make_params(xyz_min, xyz_max, stepdist, nullptr, nullptr, 0, 0, 0, X, Y, Z, 0.f, 0.f, 0.f);
   hipStream_t s = (hipStream_t)stream;
   const int variant = g_tuning[DVGO_TUNE_FEAT_BWD];
-  const bool dense_cl = (sC == 1) && (sZ == C) && (sY == (int64_t)Z * C) && (sX == (int64_t)Y * Z * C) &&
-                        ((int64_t)X * Y * Z < ((int64_t)1 << 31)) && ((((uintptr_t)grad_feat) & 15) == 0);
-  if (variant == 1 && dense_cl && (C == 12 || C == 4 || C == 8 || C == 16)) {
-    const int64_t n_pass = (M3 + 31) / 32;
-    const int blocks = (int)((n_pass + 3) / 4 < 4096 ? (n_pass + 3) / 4 : 4096);
-    if (C == 12) march_feat_bwd_dedup_kernel<12><<<blocks, DVGO_BLOCK, 0, s>>>(grad_feat, ray_id, step_id, M3, rays_start, rays_dir, P, grad_k0);
-    else if (C == 4) march_feat_bwd_dedup_kernel<4><<<blocks, DVGO_BLOCK, 0, s>>>(grad_feat, ray_id, step_id, M3, rays_start, rays_dir, P, grad_k0);
-    else if (C == 8) march_feat_bwd_dedup_kernel<8><<<blocks, DVGO_BLOCK, 0, s>>>(grad_feat, ray_id, step_id, M3, rays_start, rays_dir, P, grad_k0);
-    else march_feat_bwd_dedup_kernel<16><<<blocks, DVGO_BLOCK, 0, s>>>(grad_feat, ray_id, step_id, M3, rays_start, rays_dir, P, grad_k0);
+  // voxel-major rows of RS = sZ floats (RS == C: the channels-last gradient itself; RS == 16: 64-byte rows of a
+  // combined gradient buffer)
+  const bool rows = (sC == 1) && (sZ >= C) && (sY == (int64_t)Z * sZ) && (sX == (int64_t)Y * Z * sZ) &&
+                    ((int64_t)X * Y * Z < ((int64_t)1 << 31)) && ((((uintptr_t)grad_feat) & 15) == 0);
+  const int RS = (int)sZ;
+  const int64_t n_pass = (M3 + 31) / 32;
+  const int blocks = (int)((n_pass + 3) / 4 < 4096 ? (n_pass + 3) / 4 : 4096);
+#define DVGO_FEAT_BWD(CC, EX)                                                                             \
+  march_feat_bwd_dedup_kernel<CC, EX><<<blocks, DVGO_BLOCK, 0, s>>>(grad_feat, grad_extra, ray_id, step_id, M3, rays_start, \
+                                                                     rays_dir, P, grad_k0, RS)
+  if (grad_extra != nullptr) {      // the extra channel is only built for the 12-feature, row-layout case
+    if (!(rows && C == 12 && sZ >= C + 1)) return DVGO_ERANGE;
+    DVGO_FEAT_BWD(12, true);
+  } else if (variant == 1 && rows && (C == 12 || C == 4 || C == 8 || C == 16)) {
+    if (C == 12) DVGO_FEAT_BWD(12, false);
+    else if (C == 4) DVGO_FEAT_BWD(4, false);
+    else if (C == 8) DVGO_FEAT_BWD(8, false);
+    else DVGO_FEAT_BWD(16, false);
   } else {
     march_feat_bwd_kernel<<<dvgo_blocks(M3 * C, DVGO_BLOCK), DVGO_BLOCK, 0, s>>>(
         grad_feat, ray_id, step_id, M3, rays_start, rays_dir, P, C, sC, sX, sY, sZ, grad_k0);
   }
+#undef DVGO_FEAT_BWD
+  DVGO_LAUNCH_CHECK();
+  return 0;
+}
+
+// combined gradient rows [n_vox][RS] -> channels-last feature gradient [n_vox][C] and density gradient [n_vox]
+__global__ void __launch_bounds__(DVGO_BLOCK)
+grid_grad_split_kernel(const float* __restrict__ G, int64_t n_vox, float* __restrict__ grad_k0,
+                       float* __restrict__ grad_density) {
+  // 16-float rows, 12 + 1 channels: 4 lanes per row, float4 each
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t row = t >> 2;
+  const int q = (int)(t & 3);
+  if (row >= n_vox) return;
+  const float4 v = reinterpret_cast<const float4*>(G)[row * 4 + q];
+  if (q < 3) reinterpret_cast<float4*>(grad_k0)[row * 3 + q] = v;
+  else grad_density[row] = v.x;
+}
+
+int dvgo_grid_grad_split(const float* G, int64_t n_vox, int row_stride, int C, float* grad_k0, float* grad_density,
+                         void* stream) {
+  if (n_vox < 0) return DVGO_EINVAL;
+  if (n_vox == 0) return 0;
+  if (!G || !grad_k0 || !grad_density) return DVGO_EINVAL;
+  if (row_stride != 16 || C != 12) return DVGO_ERANGE;
+  if (!dvgo_fits(n_vox * 4)) return DVGO_ERANGE;
+  grid_grad_split_kernel<<<dvgo_blocks(n_vox * 4, DVGO_BLOCK), DVGO_BLOCK, 0, (hipStream_t)stream>>>(G, n_vox, grad_k0,
+                                                                                                   grad_density);
   DVGO_LAUNCH_CHECK();
   return 0;
 }
@@ -763,24 +813,24 @@ int dvgo_march_density_bwd(const dvgo_rec2_t* rec2, const int32_t* n2, const int
                            const float* rays_start, const float* rays_dir, float stepdist,
                            const float* xyz_min, const float* xyz_max, const float* alphainv_last,
                            float interval, const float* grad_weights, const float* grad_last, int X,
-                           int Y, int Z, float* grad_density, void* stream) {
+                           int Y, int Z, float* grad_density, int64_t grad_stride, float* grad_kept, void* stream) {
   if (n_rays < 0 || X <= 0 || Y <= 0 || Z <= 0) return DVGO_EINVAL;
   if (n_rays == 0) return 0;
   if (!rec2 || !n2 || !n_steps || !off3 || !rays_start || !rays_dir || !xyz_min ||
       !xyz_max || !alphainv_last || !grad_density)
     return DVGO_EINVAL;       // grad_weights may be NULL when M3 == 0 (it is only read for flagged samples)
-  if (!n_steps_cumsum && rec_stride <= 0) return DVGO_EINVAL;
+  if ((!n_steps_cumsum && rec_stride <= 0) || grad_stride <= 0) return DVGO_EINVAL;
   if (!dvgo_fits(n_rays * 64)) return DVGO_ERANGE;
   const MarchParams P = make_params(xyz_min, xyz_max, stepdist, nullptr, nullptr, 0, 0, 0, X, Y, Z, 0.f,
                                     interval, 0.f);
   if (g_tuning[DVGO_TUNE_DENSITY_BWD] == 1 && (int64_t)X * Y * Z < ((int64_t)1 << 31))
     march_density_bwd_kernel<true><<<dvgo_blocks(n_rays * 64, DVGO_BLOCK), DVGO_BLOCK, 0, (hipStream_t)stream>>>(
         rec2, n2, n_steps, n_steps_cumsum, rec_stride, off3, n_rays, rays_start, rays_dir, P, alphainv_last,
-        grad_weights, grad_last, grad_density);
+        grad_weights, grad_last, grad_density, grad_stride, grad_kept);
   else
     march_density_bwd_kernel<false><<<dvgo_blocks(n_rays * 64, DVGO_BLOCK), DVGO_BLOCK, 0, (hipStream_t)stream>>>(
         rec2, n2, n_steps, n_steps_cumsum, rec_stride, off3, n_rays, rays_start, rays_dir, P, alphainv_last,
-        grad_weights, grad_last, grad_density);
+        grad_weights, grad_last, grad_density, grad_stride, grad_kept);
   DVGO_LAUNCH_CHECK();
   return 0;
 }

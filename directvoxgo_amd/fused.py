@@ -61,6 +61,10 @@ def _rec_stride(cfg, n_rays):
     return stride
 
 
+# A/B switch (tests, tools): scatter both grid gradients through one buffer of 64-byte voxel rows
+COMBINED_GRID_GRAD = True
+
+
 class _FusedMarch(torch.autograd.Function):
     @staticmethod
     def forward(ctx, density, k0, rays_o, rays_d, cfg):
@@ -142,20 +146,47 @@ class _FusedMarch(torch.autograd.Function):
         M3 = ray_id.shape[0]
         st = stream_of(start)
         grad_density = grad_k0 = None
+        dev = start.device
         with torch.cuda.device_of(start):
-            if ctx.needs_input_grad[1] and g_feat is not None and C > 0:
-                grad_k0 = torch.zeros_like(ctx.k0_meta, memory_format=torch.preserve_format)
-                assert grad_k0.stride() == ctx.k0_meta.stride()
-                L.call('dvgo_march_feat_bwd', ptr(g_feat.contiguous()), ptr(ray_id), ptr(step_id), _i64(M3),
-                       ptr(start), ptr(dirs), _flt(cfg.stepdist), cfg.xyz_min_h, cfg.xyz_max_h, _int(C), _int(X),
-                       _int(Y), _int(Z), _i64(sC), _i64(sX), _i64(sY), _i64(sZ), ptr(grad_k0), st)
-            if ctx.needs_input_grad[0]:
-                grad_density = torch.zeros_like(ctx.density_meta)
-                gw = g_w.contiguous() if g_w is not None else torch.zeros(M3, dtype=torch.float32, device=start.device)
+            want_k0 = ctx.needs_input_grad[1] and g_feat is not None and C > 0
+            want_d = ctx.needs_input_grad[0]
+            gw = gl = None
+            if want_d:
+                gw = g_w.contiguous() if g_w is not None else torch.zeros(M3, dtype=torch.float32, device=dev)
                 gl = g_last.contiguous() if g_last is not None else None
+
+            def density_bwd(dst, dst_stride, kept):
                 L.call('dvgo_march_density_bwd', ptr(rec2), ptr(n2), ptr(n_steps), cum_p, _i64(stride), ptr(off3),
                        _i64(N), ptr(start), ptr(dirs), _flt(cfg.stepdist), cfg.xyz_min_h, cfg.xyz_max_h, ptr(last),
-                       _flt(cfg.interval), ptr(gw), ptr(gl), _int(X), _int(Y), _int(Z), ptr(grad_density), st)
+                       _flt(cfg.interval), ptr(gw), ptr(gl), _int(X), _int(Y), _int(Z), ptr(dst), _i64(dst_stride),
+                       ptr(kept), st)
+
+            combined = (COMBINED_GRID_GRAD and want_k0 and want_d and C == 12 and M3 > 0 and tuple(ctx.density_meta.shape[2:]) == (X, Y, Z)
+                        and (sC, sZ, sY, sX) == (1, C, Z * C, Y * Z * C))
+            if combined:
+                # both grids share the voxel lattice: one scatter into 64-byte rows (12 feature channels + the
+                # density gradient), then a streaming split into the two dense gradients
+                G = torch.zeros((X * Y * Z, 16), dtype=torch.float32, device=dev)
+                kept = torch.empty(M3, dtype=torch.float32, device=dev)
+                density_bwd(G[:, 12:], 16, kept)
+                L.call('dvgo_march_feat_bwd', ptr(g_feat.contiguous()), ptr(kept), ptr(ray_id), ptr(step_id), _i64(M3),
+                       ptr(start), ptr(dirs), _flt(cfg.stepdist), cfg.xyz_min_h, cfg.xyz_max_h, _int(C), _int(X),
+                       _int(Y), _int(Z), _i64(1), _i64(Y * Z * 16), _i64(Z * 16), _i64(16), ptr(G), st)
+                grad_k0 = torch.empty_like(ctx.k0_meta, memory_format=torch.preserve_format)
+                grad_density = torch.empty_like(ctx.density_meta)
+                assert grad_k0.stride() == ctx.k0_meta.stride() and grad_density.is_contiguous()
+                L.call('dvgo_grid_grad_split', ptr(G), _i64(X * Y * Z), _int(16), _int(C), ptr(grad_k0),
+                       ptr(grad_density), st)
+            else:
+                if want_k0:
+                    grad_k0 = torch.zeros_like(ctx.k0_meta, memory_format=torch.preserve_format)
+                    assert grad_k0.stride() == ctx.k0_meta.stride()
+                    L.call('dvgo_march_feat_bwd', ptr(g_feat.contiguous()), ptr(None), ptr(ray_id), ptr(step_id),
+                           _i64(M3), ptr(start), ptr(dirs), _flt(cfg.stepdist), cfg.xyz_min_h, cfg.xyz_max_h, _int(C),
+                           _int(X), _int(Y), _int(Z), _i64(sC), _i64(sX), _i64(sY), _i64(sZ), ptr(grad_k0), st)
+                if want_d:
+                    grad_density = torch.zeros_like(ctx.density_meta)
+                    density_bwd(grad_density, 1, None)
         return grad_density, grad_k0, None, None, None
 
 

@@ -240,16 +240,25 @@ int dvgo_march_composite_bwd(const float* grad_rgb_marched /* [N,3] */, const fl
                              float bg, float* grad_weights /* [M3] */, float* grad_rgb /* [M3,3] */,
                              float* grad_last_add, void* stream);
 
-/* dvgo_march_feat_bwd: scatter grad_feat [M3,C] into grad_k0 (float atomics; strides of k0). */
-int dvgo_march_feat_bwd(const float* grad_feat, const int64_t* ray_id, const int64_t* step_id,
+/* dvgo_march_feat_bwd: scatter grad_feat [M3,C] into grad_k0 (float atomics, de-duplicated per wavefront in LDS;
+ *   element strides sC,sX,sY,sZ of the destination).
+ *   grad_extra (NULL or [M3]): one more per-sample scalar scattered with the same trilinear weights as channel C
+ *   of the same voxel row -- used with a combined gradient buffer of 64-byte rows (sC = 1, sZ = 16 floats: 12
+ *   feature channels, the density gradient, 3 pad): float atomics are bound by 64-B requests, an aligned row is
+ *   exactly one, and the density gradient of the kept samples then costs no request of its own.  Needs
+ *   C == 12 and a row layout with sZ > C, else DVGO_ERANGE. */
+int dvgo_march_feat_bwd(const float* grad_feat, const float* grad_extra, const int64_t* ray_id, const int64_t* step_id,
                         int64_t M3, const float* rays_start, const float* rays_dir, float stepdist,
                         const float* xyz_min, const float* xyz_max,
                         int C, int X, int Y, int Z, int64_t sC, int64_t sX, int64_t sY, int64_t sZ,
                         float* grad_k0, void* stream);
 
 /* dvgo_march_density_bwd: one wavefront per ray.  alpha2weight backward (K13) over the rec2
- *   samples, raw2alpha backward (K10), then the trilinear scatter into grad_density [X,Y,Z].
- *   grad_weights is indexed in the M3 order of dvgo_march_gather; grad_last may be NULL (= 0). */
+ *   samples, raw2alpha backward (K10), then the trilinear scatter into grad_density (voxel v at
+ *   grad_density[v * grad_stride]; 1 for the plain [X,Y,Z] grid).
+ *   grad_weights is indexed in the M3 order of dvgo_march_gather; grad_last may be NULL (= 0).
+ *   grad_kept (NULL or [M3]): when given, the samples kept by dvgo_march_gather write their density gradient there
+ *   (for dvgo_march_feat_bwd's grad_extra) instead of scattering it; only the dropped ones are scattered here. */
 int dvgo_march_density_bwd(const dvgo_rec2_t* rec2, const int32_t* n2, const int64_t* n_steps,
                            const int64_t* n_steps_cumsum, int64_t rec_stride, const int64_t* off3,
                            int64_t n_rays,
@@ -257,7 +266,13 @@ int dvgo_march_density_bwd(const dvgo_rec2_t* rec2, const int32_t* n2, const int
                            const float* xyz_min, const float* xyz_max,
                            const float* alphainv_last, float interval,
                            const float* grad_weights /* [M3] */, const float* grad_last /* [N] */,
-                           int X, int Y, int Z, float* grad_density, void* stream);
+                           int X, int Y, int Z, float* grad_density, int64_t grad_stride, float* grad_kept,
+                           void* stream);
+
+/* Combined gradient rows G [n_vox][row_stride] (built by the two calls above) -> the channels-last feature
+ * gradient [n_vox][C] and the density gradient [n_vox], both fully written.  Built for row_stride 16, C 12. */
+int dvgo_grid_grad_split(const float* G, int64_t n_vox, int row_stride, int C, float* grad_k0, float* grad_density,
+                         void* stream);
 
 /* ---------------------------------------------------------------------------------
  * "next" row N3: fused colour head (rgbnet) forward.  Replaces lib/dvgo.py:516-541 for the

@@ -124,10 +124,13 @@ def test_fused_equals_unfused_on_larger_scene():
     from directvoxgo_amd.scenes import synthetic_scene
     torch.manual_seed(0)
     sc = synthetic_scene(world=48, n_rays=2048, seed=3, device='cuda')
+    from directvoxgo_amd import fused as fused_mod
     outs = {}
-    for fused in (True, False):
+    # 'separate': the fused march with one scatter per grid instead of the combined 64-byte gradient rows
+    for fused in (True, 'separate', False):
+        fused_mod.COMBINED_GRID_GRAD = fused is True
         m = DirectVoxGO(sc['xyz_min'], sc['xyz_max'], num_voxels=48 ** 3, num_voxels_base=48 ** 3, alpha_init=1e-2,
-                        fast_color_thres=1e-4, rgbnet_dim=12, rgbnet_width=32, fused=fused)
+                        fast_color_thres=1e-4, rgbnet_dim=12, rgbnet_width=32, fused=bool(fused))
         torch.manual_seed(1)
         for p in m.rgbnet.parameters():
             torch.nn.init.normal_(p, std=0.2)
@@ -139,6 +142,10 @@ def test_fused_equals_unfused_on_larger_scene():
         loss = loss_fn(res, sc['target'], 2048, 0.001, 0.01)
         loss.backward()
         outs[fused] = (res, m.density.grad.clone(), m.k0.grad.clone())
+    fused_mod.COMBINED_GRID_GRAD = True
+    assert (outs[True][1] != 0).sum() == (outs['separate'][1] != 0).sum()      # same voxels touched (masked Adam)
+    for k in (1, 2):      # the two fused variants differ by atomic summation order only
+        assert (outs[True][k] - outs['separate'][k]).abs().max() <= 1e-5 * outs['separate'][k].abs().max()
     a, b = outs[True][0], outs[False][0]
     assert abs(a['weights'].numel() - b['weights'].numel()) <= 4
     assert torch.allclose(a['rgb_marched'], b['rgb_marched'], atol=2e-5)

@@ -29,7 +29,7 @@ with torch.no_grad():
     m.density.copy_(sc['density']); m.k0.copy_(sc['k0']); m.mask_cache.mask.copy_(sc['mask'])
 rk = dict(near=sc['near'], far=sc['far'], bg=1, stepsize=0.5)
 NAMES = ['dvgo_sample_pts_prepare', 'dvgo_march_density', 'dvgo_exclusive_scan_i32', 'dvgo_march_gather',
-         'dvgo_march_composite', 'dvgo_march_composite_bwd', 'dvgo_march_feat_bwd', 'dvgo_march_density_bwd']
+         'dvgo_march_composite', 'dvgo_march_composite_bwd', 'dvgo_march_feat_bwd', 'dvgo_march_density_bwd', 'dvgo_grid_grad_split']
 
 
 def one_pass():
@@ -41,8 +41,12 @@ def one_pass():
 
 
 def run(tuning, rounds):
+    from directvoxgo_amd import fused
     for k, v in tuning.items():
-        L.call('dvgo_set_tuning', ctypes.c_int(k), ctypes.c_int(v))
+        if k == 'combined':
+            fused.COMBINED_GRID_GRAD = v
+        else:
+            L.call('dvgo_set_tuning', ctypes.c_int(k), ctypes.c_int(v))
     one_pass()
     torch.cuda.synchronize()
     per = {n: [] for n in NAMES}
@@ -55,7 +59,8 @@ def run(tuning, rounds):
     return per, m.k0.grad.clone(), m.density.grad.clone()
 
 
-variants = {'base(0,0)': {0: 0, 1: 0}, 'dedup(1,1)': {0: 1, 1: 1}}
+variants = {'base(0,0)': {0: 0, 1: 0, 'combined': False}, 'dedup(1,1)': {0: 1, 1: 1, 'combined': False},
+            'combined rows': {0: 1, 1: 1, 'combined': True}}
 results = {}
 for r in range(2):               # interleave
     for name, t in variants.items():
