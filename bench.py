@@ -134,8 +134,6 @@ def timed_region(step_fn, pool, steps, warmup, world, profile=True):
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    if profile:
-        L.profile_start(HOT_KERNELS)
     t0 = time.perf_counter()
     for i in range(steps):
         step_fn(*pool[(warmup + i) % len(pool)], global_step=5000 + warmup + i)
@@ -143,7 +141,20 @@ def timed_region(step_fn, pool, steps, warmup, world, profile=True):
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    prof = L.profile_stop() if profile else {}
+    prof = {}
+    if profile:
+        # per-kernel durations: the same K steps again with every kernel on ONE stream.  In the timed region above
+        # the colour head's weight-gradient kernel runs on a second stream beside the grid scatters, and an event
+        # pair around a kernel that shares the machine measures the sharing, not the kernel.
+        overlap, step_fn.overlap_wgrad = step_fn.overlap_wgrad, False
+        step_fn(*pool[0], global_step=5000 + warmup + steps)
+        torch.cuda.synchronize()
+        L.profile_start(HOT_KERNELS)
+        for i in range(steps):
+            step_fn(*pool[(warmup + i) % len(pool)], global_step=5001 + warmup + steps + i)
+        torch.cuda.synchronize()
+        prof = L.profile_stop()
+        step_fn.overlap_wgrad = overlap
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -295,6 +306,7 @@ def main():
                                f'(M_d={M_d}, M_k={M_k} per GPU per step), full train step',
                    'rays_per_gpu': args.rays, 'grid': args.world, 'parallelism': f'ray-dp{world}'},
         'roofline': roofline, 'north_star_kernels': ns, 'kernels': kernels,
+        'kernel_timing': 'HIP events around each launch, second pass of the same K steps with all kernels on one stream',
     }
 
     if rank == 0 and world == 1 and not args.no_secondary and args.workload == 'roofline':

@@ -15,11 +15,19 @@ N_PARTS = 512     # max workgroups (= partial sums) of the weight-gradient kerne
 
 
 class defer_wgrad:
-    """Context manager: inside it, the colour head's backward only produces the data gradient and queues its
-    weight-gradient kernel; `flush()` runs the queued work and accumulates into the parameters' `.grad`.
-    The training step uses it to start the (large) grid-gradient all-reduce before the weight gradients are
-    computed, so that communication overlaps with that kernel."""
+    """Context manager: inside it, the colour head's backward only produces the data gradient and hands its
+    weight-gradient kernel to this object; `flush()` accumulates the results into the parameters' `.grad`.
+
+    The weight-gradient kernel (fp32 MFMA, ~1 ms on the roofline case) and what autograd runs next -- the
+    grid-gradient scatters, bound by atomic requests, then in data-parallel runs the grid all-reduce -- use
+    different parts of the machine, so with `side_stream=True` (default) the kernel is launched right away
+    on a second HIP stream and runs CONCURRENTLY with them; `flush()` joins the streams.  With
+    `side_stream=False` the kernel is merely postponed to `flush()` on the calling stream."""
     _active = None
+    _streams = {}
+
+    def __init__(self, side_stream=True):
+        self.side_stream = side_stream
 
     def __enter__(self):
         self.pending = []
@@ -30,10 +38,29 @@ class defer_wgrad:
         defer_wgrad._active = None
         return False
 
+    def submit(self, params, fn, device):
+        if not self.side_stream:
+            self.pending.append((params, fn, None, None))
+            return
+        side = defer_wgrad._streams.get(device)
+        if side is None:
+            side = defer_wgrad._streams[device] = torch.cuda.Stream(device=device)
+        main = torch.cuda.current_stream(device)
+        side.wait_stream(main)                 # the data-gradient kernel's outputs are this kernel's inputs
+        with torch.cuda.stream(side):
+            grads = fn()                       # launched now; `fn` keeps its operand tensors alive until flush()
+            done = torch.cuda.Event()
+            done.record(side)
+        self.pending.append((params, fn, grads, done))
+
     @torch.no_grad()
     def flush(self):
-        for params, fn in self.pending:
-            for p, g in zip(params, fn()):
+        for params, fn, grads, done in self.pending:
+            if grads is None:
+                grads = fn()
+            else:
+                torch.cuda.current_stream(grads[0].device).wait_event(done)
+            for p, g in zip(params, grads):
                 if p.requires_grad:
                     p.grad = g if p.grad is None else p.grad + g
         self.pending = []
@@ -123,7 +150,7 @@ class _Shade(torch.autograd.Function):
 
         gf = g_feat if ctx.needs_input_grad[0] else None
         if defer_wgrad._active is not None:
-            defer_wgrad._active.pending.append((ctx.params, wgrad))
+            defer_wgrad._active.submit(ctx.params, wgrad, feat.device)
             return (gf, None, None, None, None, None, None, None, None, None)
         gW1, gb1, gW2, gb2, gW3, gb3 = wgrad()
         return (gf, None, None, gW1, gb1, gW2, gb2, gW3, gb3, None)

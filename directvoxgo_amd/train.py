@@ -121,8 +121,10 @@ def fused_render_loss(render_result, target, n_rays_global, cfg_train):
 class TrainStep:
     """One optimisation step on one batch of rays; ``world_size > 1`` shards the batch by rank."""
 
-    def __init__(self, model, cfg_train, render_kwargs, optimizer=None, process_group=None, fused_loss=True):
+    def __init__(self, model, cfg_train, render_kwargs, optimizer=None, process_group=None, fused_loss=True,
+                 overlap_wgrad=True):
         self.model = model
+        self.overlap_wgrad = overlap_wgrad    # colour-head weight gradients on a second stream (shade.defer_wgrad)
         self.fused_loss = fused_loss
         self.cfg = cfg_train
         self.render_kwargs = render_kwargs
@@ -171,9 +173,10 @@ class TrainStep:
         self.optimizer.zero_grad(set_to_none=True)
         loss_fn = fused_render_loss if (self.fused_loss and res['rgb_marched'].is_cuda) else render_loss
         loss = loss_fn(res, target, n_global, cfg)
-        # backward order: ... colour-head data gradient -> grid scatters; the colour head's weight-gradient
-        # kernel is deferred until the grid all-reduce has been started, so RCCL overlaps with it
-        with defer_wgrad() as deferred:
+        # backward order: ... colour-head data gradient -> grid scatters.  The colour head's weight-gradient kernel
+        # runs on a second stream beside the scatters and, in data-parallel runs, beside the grid all-reduce that
+        # is started as soon as the scatters are queued
+        with defer_wgrad(side_stream=self.overlap_wgrad) as deferred:
             loss.backward()
         works = self.reduce_grids_async()
         deferred.flush()
