@@ -10,7 +10,7 @@ feat = torch.randn(M, 12, device='cuda', requires_grad=True)
 emb = torch.randn(N, 27, device='cuda'); ray_id = torch.arange(M, device='cuda') // 256
 go = torch.randn(M, 3, device='cuda')
 NAMES = ['dvgo_shade_fwd', 'dvgo_shade_bwd', 'dvgo_shade_wgrad']
-for flag in (0, 1, 0, 1):
+for flag in [int(a) for a in sys.argv[1:]] or (0, 1, 0, 1):
     L.lib().dvgo_shade_experiment(ctypes.c_int(flag))
     for _ in range(2):
         shade(net, feat, emb, ray_id, True).backward(go)
