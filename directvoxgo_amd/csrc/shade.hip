@@ -532,6 +532,23 @@ shade_wgrad_kernel(const float* __restrict__ G1, const float* __restrict__ gz, c
   }
 }
 
+// sum of the per-workgroup partials: [n_parts][n] -> [n]  (coalesced across threads, 4 rows in flight per thread)
+__global__ void __launch_bounds__(256)
+shade_wgrad_reduce_kernel(const float* __restrict__ part, int n_parts, int n, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+  int p = 0;
+  for (; p + 4 <= n_parts; p += 4) {
+    a0 += part[(int64_t)p * n + i];
+    a1 += part[(int64_t)(p + 1) * n + i];
+    a2 += part[(int64_t)(p + 2) * n + i];
+    a3 += part[(int64_t)(p + 3) * n + i];
+  }
+  for (; p < n_parts; ++p) a0 += part[(int64_t)p * n + i];
+  out[i] = (a0 + a1) + (a2 + a3);
+}
+
 extern "C" {
 
 int dvgo_shade_fwd(const float* feat, int C, const float* emb, int E, const int64_t* ray_id, int64_t M,
@@ -585,14 +602,17 @@ int dvgo_shade_bwd(const float* g_rgb, const float* rgb, const uint64_t* masks, 
 
 int dvgo_shade_wgrad(const float* G1, const float* gz, const uint64_t* masks, const float* W3, const float* H1,
                      const float* H2, const float* feat, int C, const float* emb, int E, const int64_t* ray_id, int64_t M, int width,
-                     int diffuse, int n_parts, float* part, void* stream) {
+                     int diffuse, int n_parts, float* part, float* total, void* stream) {
   if (M < 0 || n_parts <= 0 || C <= 0 || E < 0) return DVGO_EINVAL;
-  if (!G1 || !gz || !masks || !W3 || !H1 || !H2 || !feat || !emb || !ray_id || !part) return DVGO_EINVAL;
+  if (!G1 || !gz || !masks || !W3 || !H1 || !H2 || !feat || !emb || !ray_id || !part || !total) return DVGO_EINVAL;
   const int c_view0 = diffuse ? 3 : 0;
   const int n_view = C - c_view0;
   if (width != 128 || n_view < 0 || n_view + E > 40) return DVGO_ERANGE;
   shade_wgrad_kernel<128><<<n_parts, 256, 0, (hipStream_t)stream>>>(
       G1, gz, (const unsigned int*)masks, W3, H1, H2, feat, C, c_view0, n_view, emb, E, ray_id, M, part);
+  DVGO_LAUNCH_CHECK();
+  const int psize = width * width + width * 64 + 32 * width + 3 * width;
+  shade_wgrad_reduce_kernel<<<(psize + 255) / 256, 256, 0, (hipStream_t)stream>>>(part, n_parts, psize, total);
   DVGO_LAUNCH_CHECK();
   return 0;
 }

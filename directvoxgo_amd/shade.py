@@ -136,11 +136,11 @@ class _Shade(torch.autograd.Function):
             n_parts = max(1, min(N_PARTS, (M + 511) // 512))      # >= 16 row tiles per workgroup on small batches
             psize = width * width + width * 64 + 32 * width + 3 * width
             part = torch.empty((n_parts, psize), dtype=torch.float32, device=feat.device)
+            tot = torch.empty(psize, dtype=torch.float32, device=feat.device)
             with torch.cuda.device_of(feat):
                 L.call('dvgo_shade_wgrad', ptr(G1), ptr(gz), ptr(masks), ptr(W3.contiguous()), ptr(H1), ptr(H2), ptr(feat), _int(C), ptr(emb),
                        _int(emb.shape[1]), ptr(ray_id), _i64(M), _int(width), _int(1 if diffuse else 0), _int(n_parts),
-                       ptr(part), stream_of(feat))
-            tot = part.sum(0)
+                       ptr(part), ptr(tot), stream_of(feat))
             o = 0
             gW2 = tot[o:o + width * width].view(width, width); o += width * width
             gW1 = tot[o:o + width * 64].view(width, 64)[:, :d_in]; o += width * 64
