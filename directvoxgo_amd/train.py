@@ -173,10 +173,11 @@ class TrainStep:
         self.optimizer.zero_grad(set_to_none=True)
         loss_fn = fused_render_loss if (self.fused_loss and res['rgb_marched'].is_cuda) else render_loss
         loss = loss_fn(res, target, n_global, cfg)
-        # backward order: ... colour-head data gradient -> grid scatters.  The colour head's weight-gradient kernel
-        # runs on a second stream beside the scatters and, in data-parallel runs, beside the grid all-reduce that
-        # is started as soon as the scatters are queued
-        with defer_wgrad(side_stream=self.overlap_wgrad) as deferred:
+        # backward order: ... colour-head data gradient -> grid scatters.  One GPU: the colour head's weight-gradient
+        # kernel runs on a second stream beside the scatters.  Data parallel: it is postponed until the grid
+        # all-reduce has been STARTED -- its persistent workgroups fill every CU, and RCCL's kernels, arriving
+        # second, would sit behind them; arriving first they keep their CUs and the two overlap
+        with defer_wgrad(side_stream=self.overlap_wgrad and self.world == 1) as deferred:
             loss.backward()
         works = self.reduce_grids_async()
         deferred.flush()
