@@ -63,6 +63,7 @@ def _rec_stride(cfg, n_rays):
 
 # A/B switch (tests, tools): scatter both grid gradients through one buffer of 64-byte voxel rows
 COMBINED_GRID_GRAD = True
+COMBINED_MIN_RATIO = 6          # use it when kept samples * ratio >= voxels (tests set 1e9 to force it)
 
 
 class _FusedMarch(torch.autograd.Function):
@@ -161,7 +162,8 @@ class _FusedMarch(torch.autograd.Function):
                        _flt(cfg.interval), ptr(gw), ptr(gl), _int(X), _int(Y), _int(Z), ptr(dst), _i64(dst_stride),
                        ptr(kept), st)
 
-            combined = (COMBINED_GRID_GRAD and want_k0 and want_d and C == 12 and M3 > 0 and tuple(ctx.density_meta.shape[2:]) == (X, Y, Z)
+            # worth its two extra full-grid passes (zero 64 B, split 116 B per voxel) from ~1 kept sample per 6 voxels
+            combined = (COMBINED_GRID_GRAD and want_k0 and want_d and C == 12 and M3 * COMBINED_MIN_RATIO >= X * Y * Z and tuple(ctx.density_meta.shape[2:]) == (X, Y, Z)
                         and (sC, sZ, sY, sX) == (1, C, Z * C, Y * Z * C))
             if combined:
                 # both grids share the voxel lattice: one scatter into 64-byte rows (12 feature channels + the

@@ -133,7 +133,7 @@ class _Shade(torch.autograd.Function):
                    ptr(g_feat), ptr(G1), ptr(gz), stream_of(feat))
 
         def wgrad():
-            n_parts = max(1, min(N_PARTS, (M + 511) // 512))      # >= 16 row tiles per workgroup on small batches
+            n_parts = max(1, min(N_PARTS, (M + 255) // 256))      # >= 8 row tiles per workgroup on small batches
             psize = width * width + width * 64 + 32 * width + 3 * width
             part = torch.empty((n_parts, psize), dtype=torch.float32, device=feat.device)
             tot = torch.empty(psize, dtype=torch.float32, device=feat.device)

@@ -128,7 +128,7 @@ def test_fused_equals_unfused_on_larger_scene():
     outs = {}
     # 'separate': the fused march with one scatter per grid instead of the combined 64-byte gradient rows
     for fused in (True, 'separate', False):
-        fused_mod.COMBINED_GRID_GRAD = fused is True
+        fused_mod.COMBINED_GRID_GRAD, fused_mod.COMBINED_MIN_RATIO = fused is True, 1e9    # force it on this small scene
         m = DirectVoxGO(sc['xyz_min'], sc['xyz_max'], num_voxels=48 ** 3, num_voxels_base=48 ** 3, alpha_init=1e-2,
                         fast_color_thres=1e-4, rgbnet_dim=12, rgbnet_width=32, fused=bool(fused))
         torch.manual_seed(1)
@@ -142,7 +142,7 @@ def test_fused_equals_unfused_on_larger_scene():
         loss = loss_fn(res, sc['target'], 2048, 0.001, 0.01)
         loss.backward()
         outs[fused] = (res, m.density.grad.clone(), m.k0.grad.clone())
-    fused_mod.COMBINED_GRID_GRAD = True
+    fused_mod.COMBINED_GRID_GRAD, fused_mod.COMBINED_MIN_RATIO = True, 6
     assert (outs[True][1] != 0).sum() == (outs['separate'][1] != 0).sum()      # same voxels touched (masked Adam)
     for k in (1, 2):      # the two fused variants differ by atomic summation order only
         assert (outs[True][k] - outs['separate'][k]).abs().max() <= 1e-5 * outs['separate'][k].abs().max()
