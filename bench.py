@@ -87,7 +87,9 @@ def build(workload, world, n_rays, device, seed):
         sc = synthetic_scene(world=world, n_rays=n_rays, seed=seed, device=device)
     torch.manual_seed(777)       # identical MLP init on every rank
     m = DirectVoxGO(sc['xyz_min'], sc['xyz_max'], num_voxels=world ** 3, num_voxels_base=world ** 3, alpha_init=1e-2,
-                    fast_color_thres=1e-4, rgbnet_dim=12, rgbnet_depth=3, rgbnet_width=128, viewbase_pe=4, fused=True)
+                    fast_color_thres=1e-4, rgbnet_dim=12, rgbnet_depth=3, rgbnet_width=128, viewbase_pe=4,
+                    rgbnet_direct=True,           # configs/default.py:88, what run.py builds for configs/nerf/lego.py
+                    fused=True)
     m = m.to(device)
     return sc, m
 

@@ -217,12 +217,12 @@ def gen_maskcache_path(R):
     save('maskcache_path', **out)
 
 
-def _scene(R, rng, fine=True, nvox=16 ** 3, width=32):
+def _scene(R, rng, fine=True, nvox=16 ** 3, width=32, direct=False):
     mn, mx = np.array([-1.05, -1.05, -1.05], np.float32), np.array([1.05, 1.05, 1.05], np.float32)
     kw = dict(num_voxels=nvox, num_voxels_base=nvox, alpha_init=1e-2 if fine else 1e-6,
               fast_color_thres=1e-4 if fine else 1e-7)
     if fine:
-        kw.update(rgbnet_dim=12, rgbnet_depth=3, rgbnet_width=width, viewbase_pe=4)
+        kw.update(rgbnet_dim=12, rgbnet_depth=3, rgbnet_width=width, viewbase_pe=4, rgbnet_direct=direct)
     else:
         kw.update(rgbnet_dim=0)
     torch.manual_seed(777)
@@ -248,11 +248,13 @@ def _loss(render_result, target, n_rays, w_main=1.0, w_ent=0.001, w_per=0.01):
     return loss
 
 
-def gen_forward(R, fine, name):
+def gen_forward(R, fine, name, width=32, direct=False):
     """H1/H2: reference DirectVoxGO.forward + hit_coarse_geo + autograd backward
-    (lib/dvgo.py:412-577,618-660) on a small scene; natives = oracle."""
-    rng = np.random.default_rng(404 if fine else 405)
-    m, mn, mx = _scene(R, rng, fine)
+    (lib/dvgo.py:412-577,618-660) on a small scene; natives = oracle.
+    `forward_fine_direct` is the head of configs/default.py as run.py builds it for configs/nerf/lego.py:
+    rgbnet_direct=True (no diffuse term, all 12 features into the MLP) and width 128."""
+    rng = np.random.default_rng((404 if fine else 405) + (1000 if direct else 0))
+    m, mn, mx = _scene(R, rng, fine, width=width, direct=direct)
     ro, rd, vd = lego_like_rays(R, rng, n_views=4, H=5, W=5, focal=5 * 1111.11 / 800 * 3.0, radius=3.0)
     # two rays that miss the box entirely and one starting inside it
     ro = torch.cat([ro, torch.tensor([[3.0, 3.0, 3.0], [0.0, 0.0, 3.0], [0.1, 0.1, 0.2]])])
@@ -408,12 +410,16 @@ def gen_rays(R):
 def main():
     R = import_reference()
     try:
+        if len(sys.argv) > 1 and sys.argv[1] == 'forward_fine_direct':      # add this one fixture only
+            gen_forward(R, fine=True, name='forward_fine_direct', width=128, direct=True)
+            return
         gen_constants(R)
         gen_grid_sampler(R)
         gen_sampler_py(R)
         gen_maskcache_path(R)
         gen_forward(R, fine=True, name='forward_fine')
         gen_forward(R, fine=False, name='forward_coarse')
+        gen_forward(R, fine=True, name='forward_fine_direct', width=128, direct=True)
         gen_mpi_forward(R)
         gen_voxel_count_views(R)
         gen_masked_adam(R)

@@ -22,7 +22,11 @@ def build_model(g, fine, fused, channels_last=True):
     kw = dict(num_voxels=nv, num_voxels_base=nv, alpha_init=1e-2 if fine else 1e-6,
               fast_color_thres=float(g['fast_color_thres']), fused=fused, channels_last=channels_last)
     if fine:
-        kw.update(rgbnet_dim=12, rgbnet_depth=3, rgbnet_width=32, viewbase_pe=4)
+        # width / direct from the fixture: `forward_fine` is a 32-wide head with the diffuse term (torch MLP),
+        # `forward_fine_direct` the 128-wide rgbnet_direct head of configs/default.py (fused colour-head kernels)
+        width = int(g['rgbnet_0.weight'].shape[0])
+        direct = int(g['rgbnet_0.weight'].shape[1]) == 12 + 27
+        kw.update(rgbnet_dim=12, rgbnet_depth=3, rgbnet_width=width, viewbase_pe=4, rgbnet_direct=direct)
     m = DirectVoxGO(g['xyz_min'], g['xyz_max'], **kw)
     assert m.world_size.tolist() == g['world_size'].tolist()
     np.testing.assert_allclose(float(m.voxel_size), float(g['voxel_size']), rtol=1e-7)
@@ -46,10 +50,13 @@ def loss_fn(res, target, n_rays, w_ent, w_per):
 
 
 @pytest.mark.parametrize('fused', [True, False])
-@pytest.mark.parametrize('name,fine', [('forward_fine', True), ('forward_coarse', False)])
+@pytest.mark.parametrize('name,fine', [('forward_fine', True), ('forward_coarse', False), ('forward_fine_direct', True)])
 def test_forward_matches_reference_orchestration(name, fine, fused):
     g = load_golden(name)
     m = build_model(g, fine, fused)
+    if name == 'forward_fine_direct' and fused:
+        from directvoxgo_amd.shade import head_layers
+        assert m.fused_shade and head_layers(m.rgbnet) is not None       # the MFMA colour head is what runs here
     if fine:
         assert m.k0.stride()[1] == 1            # feature grid is stored channels-last
     ro, rd, vd = cu(g['rays_o']), cu(g['rays_d']), cu(g['viewdirs'])

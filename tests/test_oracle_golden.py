@@ -227,7 +227,7 @@ def test_segment_sum(oracle):
 
 
 # ---------------------------------------------------------------- orchestration fixtures are self-consistent
-@pytest.mark.parametrize('name', ['forward_fine', 'forward_coarse'])
+@pytest.mark.parametrize('name', ['forward_fine', 'forward_coarse', 'forward_fine_direct'])
 def test_forward_fixture_reproduced_by_oracle_pipeline(oracle, name):
     """Re-derive the reference forward() outputs (reference orchestration o oracle natives) with
     the oracle called directly in the reference's op order; guards the fixture and the facade."""

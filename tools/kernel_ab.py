@@ -24,7 +24,7 @@ dev = 'cuda'
 sc = roofline_scene(world=args.world, n_rays=args.rays, device=dev) if args.workload == 'roofline' else \
     synthetic_scene(world=args.world, n_rays=args.rays, device=dev)
 m = DirectVoxGO(sc['xyz_min'], sc['xyz_max'], num_voxels=args.world ** 3, num_voxels_base=args.world ** 3, alpha_init=1e-2,
-                fast_color_thres=1e-4, rgbnet_dim=12, rgbnet_width=128).to(dev)
+                fast_color_thres=1e-4, rgbnet_dim=12, rgbnet_width=128, rgbnet_direct=True).to(dev)
 with torch.no_grad():
     m.density.copy_(sc['density']); m.k0.copy_(sc['k0']); m.mask_cache.mask.copy_(sc['mask'])
 rk = dict(near=sc['near'], far=sc['far'], bg=1, stepsize=0.5)

@@ -16,7 +16,7 @@ ap.add_argument('--rounds', type=int, default=10)
 args = ap.parse_args()
 torch.manual_seed(0)
 M, N = args.M, 8192
-net = make_rgbnet(36, 128, 3).cuda()
+net = make_rgbnet(39, 128, 3).cuda()          # rgbnet_direct head of configs/default.py: 12 + 27 inputs
 feat = torch.randn(M, 12, device='cuda')
 emb = torch.randn(N, 27, device='cuda')
 ray_id = torch.arange(M, device='cuda') // (M // N)
@@ -34,24 +34,24 @@ def timeit(fn, rounds):
 
 def torch_fwd():
     with torch.no_grad():
-        x = torch.cat([feat[:, 3:], emb[ray_id]], -1)
-        return torch.sigmoid(net(x) + feat[:, :3])
+        x = torch.cat([feat, emb[ray_id]], -1)
+        return torch.sigmoid(net(x))
 
 
 def hip_infer():
     with torch.no_grad():
-        return shade(net, feat, emb, ray_id, True)
+        return shade(net, feat, emb, ray_id, False)
 
 
 fg = feat.clone().requires_grad_()
 
 
 def hip_train_fwd():
-    return shade(net, fg, emb, ray_id, True)
+    return shade(net, fg, emb, ray_id, False)
 
 
 def hip_train_fwd_bwd():
-    r = shade(net, fg, emb, ray_id, True)
+    r = shade(net, fg, emb, ray_id, False)
     r.sum().backward()
 
 
