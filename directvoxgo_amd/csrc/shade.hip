@@ -464,22 +464,21 @@ shade_wgrad_kernel(const float* __restrict__ G1, const float* __restrict__ gz, c
 #pragma unroll
     for (int i = 0; i < 5; ++i) L.x[buf][tid >> 3][(tid & 7) + 8 * i] = (pvalid && (tid & 7) + 8 * i < d_in) ? px[i] : 0.0f;
     if (tid < 128) {
+      gz_acc += pgvalid ? pgz : 0.0f;                     // db3[c] = sum of gz[:, c]: thread (row, c) of the staging
       L.gz[buf][tid >> 2][tid & 3] = pgvalid ? pgz : 0.0f;
       (&L.m2[buf][tid >> 2][0][0])[tid & 3] = pm2;
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's share of the DMA has landed (the compiler does not
     __syncthreads();                      // track LDS-DMA completion for us); X / gz / masks committed
-    const int64_t r0 = tile * 32;
+    const int rows_valid = (int)(M - tile * 32 < 32 ? M - tile * 32 : 32);      // wave-uniform
 #pragma unroll 4
     for (int s = 0; s < 16; ++s) {
       const int row = 2 * s + h;
-      const float rm = (r0 + row < M) ? 1.0f : 0.0f;
       const float4 gzr = *reinterpret_cast<const float4*>(&L.gz[buf][row][0]);      // broadcast; 0 on rows past M
       const float g2v = fmaf(w32, gzr.z, fmaf(w31, gzr.y, w30 * gzr.x));
       const float a2 = ((L.m2[buf][row][m_half][m_word] >> m_bit) & 1u) ? g2v : 0.0f;
-      const float a1 = L.g1[buf][row][32 * w + j] * rm;
+      const float a1 = row < rows_valid ? L.g1[buf][row][32 * w + j] : 0.0f;   // rows past M hold a clamped copy
       sb2 += a2; sb1 += a1;
-      gz_acc += L.gz[buf][row][j & 3];                    // lanes j < 3 are the ones read out
 #pragma unroll
       for (int t = 0; t < T; ++t)
         aW2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, L.h1[buf][row][32 * t + j], aW2[t], 0, 0, 0);
@@ -523,12 +522,15 @@ shade_wgrad_kernel(const float* __restrict__ G1, const float* __restrict__ gz, c
     const float v = vW3[c] + __shfl_xor(vW3[c], 32);
     if (h == 0) pW3[c * WIDTH + 32 * w + j] = v;
   }
-  const float gz_sum = gz_acc + __shfl_xor(gz_acc, 32);   // db3[c] = sum over rows of gz[:, c] on lanes j < 3
+  // db3[c]: the staging threads 4*row + c (waves 0 and 1, 16 rows each) hold per-row sums; fold the row bits
+  float gz_sum = gz_acc;
+  gz_sum += __shfl_xor(gz_sum, 4); gz_sum += __shfl_xor(gz_sum, 8);
+  gz_sum += __shfl_xor(gz_sum, 16); gz_sum += __shfl_xor(gz_sum, 32);
   sb1 += __shfl_xor(sb1, 32); sb2 += __shfl_xor(sb2, 32);
   if (h == 0) {
     pb[32 * w + j] = sb1;
     pb[WIDTH + 32 * w + j] = sb2;
-    if (w == 0) pb[2 * WIDTH + j] = gz_sum;
+    if (j < 8) pb[2 * WIDTH + 8 * w + j] = (w < 2 && j < 3) ? gz_sum : 0.0f;    // db3 = entries [0,3) + [8,11)
   }
 }
 

@@ -145,7 +145,8 @@ class _Shade(torch.autograd.Function):
             gW2 = tot[o:o + width * width].view(width, width); o += width * width
             gW1 = tot[o:o + width * 64].view(width, 64)[:, :d_in]; o += width * 64
             gW3 = tot[o:o + 32 * width].view(32, width)[:3]; o += 32 * width
-            gb1, gb2, gb3 = tot[o:o + width], tot[o + width:o + 2 * width], tot[o + 2 * width:o + 2 * width + 3]
+            gb1, gb2 = tot[o:o + width], tot[o + width:o + 2 * width]
+            gb3 = tot[o + 2 * width:o + 2 * width + 3] + tot[o + 2 * width + 8:o + 2 * width + 11]
             return gW1.contiguous(), gb1, gW2, gb2, gW3.contiguous(), gb3
 
         gf = g_feat if ctx.needs_input_grad[0] else None

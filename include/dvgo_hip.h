@@ -305,7 +305,7 @@ int dvgo_shade_bwd(const float* g_rgb, const float* rgb, const uint64_t* masks, 
  * ray_id exactly as in dvgo_shade_fwd), dW3 = gz^T H2 and the three bias gradients (column sums); fp32 MFMA
  * with both operands read row-major straight from memory.  Every one of the n_parts workgroups writes its
  * partial sums to part[p] = { dW2 [width][width], dW1 [width][64], dW3 [32][width] (rows 0..2 valid),
- * db1 [width], db2 [width], db3 [width] (first 3 valid) } floats (scratch), and a second launch sums them over p
+ * db1 [width], db2 [width], db3 [width] (db3[c] = entry c + entry 8+c, c < 3) } floats (scratch), and a second launch sums them over p
  * into `total` (same record layout, once). */
 int dvgo_shade_wgrad(const float* G1, const float* gz, const uint64_t* masks, const float* W3,
                      const float* H1, const float* H2, const float* feat, int C, const float* emb, int E, const int64_t* ray_id, int64_t M,
