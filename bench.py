@@ -196,7 +196,10 @@ def cpu_baseline(sc_cpu, m, rk, n_rays_total, sample_rays):
     feat = torch.from_numpy(O.grid_sample_fwd(k0, pts3, mn, mx)).requires_grad_()
     emb = (vd.unsqueeze(-1) * m.viewfreq.cpu()).flatten(-2)
     emb = torch.cat([vd, emb.sin(), emb.cos()], -1)[torch.from_numpy(rid3)]
-    rgb = torch.sigmoid(rgbnet(torch.cat([feat[:, 3:], emb], -1)) + feat[:, :3])
+    if m.rgbnet_direct:                                                   # lib/dvgo.py:517-541
+        rgb = torch.sigmoid(rgbnet(torch.cat([feat, emb], -1)))
+    else:
+        rgb = torch.sigmoid(rgbnet(torch.cat([feat[:, 3:], emb], -1)) + feat[:, :3])
     wt = torch.from_numpy(w3).requires_grad_()
     marched = torch.from_numpy(O.segment_sum((wt.detach()[:, None] * rgb.detach()).numpy(), rid3, sample_rays))
     g_marched = (2 * (marched + torch.from_numpy(last)[:, None] - sc_cpu['target'][:sample_rays]) / (3 * n_rays_total))
