@@ -534,21 +534,26 @@ shade_wgrad_kernel(const float* __restrict__ G1, const float* __restrict__ gz, c
   }
 }
 
-// sum of the per-workgroup partials: [n_parts][n] -> [n]  (coalesced across threads, 4 rows in flight per thread)
+// sum of the per-workgroup partials: [n_parts][n] -> [n].  blockIdx.y takes a slice of the parts so that a few
+// thousand wavefronts stream the 60 MB (one column block alone would leave the chip idle and latency-bound:
+// 124 us -> ~20 us); slices meet in `out` (zeroed by the caller) with one float atomic per element.
+#define SHADE_REDUCE_SLICES 16
 __global__ void __launch_bounds__(256)
 shade_wgrad_reduce_kernel(const float* __restrict__ part, int n_parts, int n, float* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  const int per = (n_parts + SHADE_REDUCE_SLICES - 1) / SHADE_REDUCE_SLICES;
+  const int p0 = blockIdx.y * per, p1 = min(n_parts, p0 + per);
   float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
-  int p = 0;
-  for (; p + 4 <= n_parts; p += 4) {
+  int p = p0;
+  for (; p + 4 <= p1; p += 4) {
     a0 += part[(int64_t)p * n + i];
     a1 += part[(int64_t)(p + 1) * n + i];
     a2 += part[(int64_t)(p + 2) * n + i];
     a3 += part[(int64_t)(p + 3) * n + i];
   }
-  for (; p < n_parts; ++p) a0 += part[(int64_t)p * n + i];
-  out[i] = (a0 + a1) + (a2 + a3);
+  for (; p < p1; ++p) a0 += part[(int64_t)p * n + i];
+  if (p1 > p0) atomicAdd(out + i, (a0 + a1) + (a2 + a3));
 }
 
 extern "C" {
@@ -614,7 +619,9 @@ int dvgo_shade_wgrad(const float* G1, const float* gz, const uint64_t* masks, co
       G1, gz, (const unsigned int*)masks, W3, H1, H2, feat, C, c_view0, n_view, emb, E, ray_id, M, part);
   DVGO_LAUNCH_CHECK();
   const int psize = width * width + width * 64 + 32 * width + 3 * width;
-  shade_wgrad_reduce_kernel<<<(psize + 255) / 256, 256, 0, (hipStream_t)stream>>>(part, n_parts, psize, total);
+  if (hipMemsetAsync(total, 0, (size_t)psize * sizeof(float), (hipStream_t)stream) != hipSuccess) return DVGO_EINVAL;
+  shade_wgrad_reduce_kernel<<<dim3((psize + 255) / 256, SHADE_REDUCE_SLICES), 256, 0, (hipStream_t)stream>>>(part, n_parts, psize,
+                                                                                                       total);
   DVGO_LAUNCH_CHECK();
   return 0;
 }
