@@ -379,13 +379,17 @@ typedef const __attribute__((address_space(1))) void* dvgo_gptr_t;
 typedef __attribute__((address_space(3))) void* dvgo_lptr_t;
 
 template <int WIDTH>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(2 * WIDTH)           // one wavefront per 32-wide out-feature tile
 shade_wgrad_kernel(const float* __restrict__ G1, const float* __restrict__ gz, const unsigned int* __restrict__ masks,
                    const float* __restrict__ W3, const float* __restrict__ H1, const float* __restrict__ H2, const float* __restrict__ feat, int C,
                    int c_view0, int n_view, const float* __restrict__ emb, int E, const int64_t* __restrict__ ray_id,
                    int64_t M, float* __restrict__ part /* [gridDim][WIDTH*WIDTH + WIDTH*64 + 32*WIDTH + 3*WIDTH] */) {
   constexpr int T = WIDTH / 32;
-  static_assert(T == 4, "one out-feature tile per wave");
+  static_assert(T == 4 || T == 2, "widths 128 and 64");
+  constexpr int TPR = 2 * T;                 // staging threads per X row (32 rows over the 64*T threads)
+  constexpr int NXI = 40 / TPR;              // X columns per staging thread (40 columns: d_in <= 40)
+  constexpr int LPR = WIDTH / 4;             // lanes per operand row in a DMA instruction (16 B per lane)
+  constexpr int RPI = 64 / LPR;              // rows per DMA wave instruction (1 KB)
   __shared__ __attribute__((aligned(16))) ShadeWgradLds<WIDTH> L;
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, j = lane & 31, w = tid >> 6;
   f32x16 aW2[T], aW1;
@@ -412,29 +416,30 @@ shade_wgrad_kernel(const float* __restrict__ G1, const float* __restrict__ gz, c
   // tile at a time; the second workgroup resident on the CU computes meanwhile.  Rows past M are read from a
   // clamped row and masked at operand read.
   // The small assembled X tile and gz travel through registers.
-  float px[5], pgz;
+  float px[NXI], pgz;
   unsigned int pm2;
   bool pvalid, pgvalid;
   int64_t ray_nx;
+  const int xrow = tid / TPR, xcol = tid - xrow * TPR;
   {
-    const int64_t row = (int64_t)blockIdx.x * 32 + (tid >> 3);
+    const int64_t row = (int64_t)blockIdx.x * 32 + xrow;
     ray_nx = ray_id[row < M ? row : M - 1];
   }
 #define SHADE_WGRAD_DMA(TILE, BUF)                                                                              \
   {                                                                                                             \
     const int64_t r0_ = (TILE) * 32;                                                                            \
     {                                                                                                           \
-      const int64_t row = r0_ + (tid >> 3);                                                                     \
+      const int64_t row = r0_ + xrow;                                                                           \
       const int64_t rc = row < M ? row : M - 1;                                                                 \
       const float* fr = feat + rc * C + c_view0;                                                                \
       const float* er = emb + ray_nx * E - n_view;      /* ray_nx was fetched one tile earlier */               \
-      _Pragma("unroll") for (int i = 0; i < 5; ++i) {   /* columns 0..39; d_in <= 40 */                         \
-        const int k = (tid & 7) + 8 * i;                                                                        \
+      _Pragma("unroll") for (int i = 0; i < NXI; ++i) { /* columns 0..39; d_in <= 40 */                         \
+        const int k = xcol + TPR * i;                                                                           \
         const int kc = k < d_in ? k : d_in - 1;                                                                 \
         px[i] = *((kc < n_view) ? fr + kc : er + kc);                                                           \
       }                                                                                                         \
       pvalid = row < M;                                                                                         \
-      const int64_t row2 = r0_ + (int64_t)gridDim.x * 32 + (tid >> 3);                                          \
+      const int64_t row2 = r0_ + (int64_t)gridDim.x * 32 + xrow;                                                \
       ray_nx = ray_id[row2 < M ? row2 : M - 1];         /* for the next tile of this workgroup */               \
     }                                                                                                           \
     {                                                                                                           \
@@ -446,10 +451,10 @@ shade_wgrad_kernel(const float* __restrict__ G1, const float* __restrict__ gz, c
       pm2 = masks[rc * 8 + 4 + (tid & 3)];                                                                      \
     }                                                                                                           \
     /* the bulk DMA goes last: the (in-order) wait for ray_nx above then costs nothing */                       \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                             \
-      const int rl = 8 * w + 2 * i;                     /* this wave instruction covers rows rl, rl + 1 */      \
-      const int64_t row = r0_ + rl + h;                                                                         \
-      const int64_t off = (row < M ? row : M - 1) * WIDTH + 4 * j;                                              \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {     /* 32 / RPI instructions per tile, 4 per wave */        \
+      const int rl = (4 * w + i) * RPI;                 /* this wave instruction covers rows rl .. rl + RPI - 1 */ \
+      const int64_t row = r0_ + rl + lane / LPR;                                                                \
+      const int64_t off = (row < M ? row : M - 1) * WIDTH + 4 * (lane % LPR);                                   \
       __builtin_amdgcn_global_load_lds((dvgo_gptr_t)(G1 + off), (dvgo_lptr_t)&L.g1[BUF][rl][0], 16, 0, 0);     \
       __builtin_amdgcn_global_load_lds((dvgo_gptr_t)(H1 + off), (dvgo_lptr_t)&L.h1[BUF][rl][0], 16, 0, 0);     \
       __builtin_amdgcn_global_load_lds((dvgo_gptr_t)(H2 + off), (dvgo_lptr_t)&L.h2[BUF][rl][0], 16, 0, 0);     \
@@ -461,8 +466,9 @@ shade_wgrad_kernel(const float* __restrict__ G1, const float* __restrict__ gz, c
     SHADE_WGRAD_DMA(tile, 0);
     // the small loads above are unconditional and all in flight together (one round trip); masked here
     asm volatile("" : "+v"(px[0]), "+v"(px[1]), "+v"(px[2]), "+v"(px[3]), "+v"(px[4]), "+v"(pgz), "+v"(pm2));
+    if (NXI > 5) asm volatile("" : "+v"(px[NXI - 5]), "+v"(px[NXI - 4]), "+v"(px[NXI - 3]), "+v"(px[NXI - 2]), "+v"(px[NXI - 1]));
 #pragma unroll
-    for (int i = 0; i < 5; ++i) L.x[buf][tid >> 3][(tid & 7) + 8 * i] = (pvalid && (tid & 7) + 8 * i < d_in) ? px[i] : 0.0f;
+    for (int i = 0; i < NXI; ++i) L.x[buf][xrow][xcol + TPR * i] = (pvalid && xcol + TPR * i < d_in) ? px[i] : 0.0f;
     if (tid < 128) {
       gz_acc += pgvalid ? pgz : 0.0f;                     // db3[c] = sum of gz[:, c]: thread (row, c) of the staging
       L.gz[buf][tid >> 2][tid & 3] = pgvalid ? pgz : 0.0f;
@@ -531,6 +537,7 @@ shade_wgrad_kernel(const float* __restrict__ G1, const float* __restrict__ gz, c
     pb[32 * w + j] = sb1;
     pb[WIDTH + 32 * w + j] = sb2;
     if (j < 8) pb[2 * WIDTH + 8 * w + j] = (w < 2 && j < 3) ? gz_sum : 0.0f;    // db3 = entries [0,3) + [8,11)
+    if (T == 2 && j >= 16) pb[2 * WIDTH + 16 * w + j] = 0.0f;                   // (rest of the db3 record: keep it defined)
   }
 }
 
@@ -569,15 +576,23 @@ int dvgo_shade_fwd(const float* feat, int C, const float* emb, int E, const int6
   const int c_view0 = diffuse ? 3 : 0;
   const int n_view = C - c_view0;
   if (n_view < 0 || d_in != n_view + E) return DVGO_EINVAL;
-  if (width != 128 || d_in > 40) return DVGO_ERANGE;     // shapes outside the instantiated set: caller falls back
+  if ((width != 128 && width != 64) || d_in > 40) return DVGO_ERANGE;   // outside the instantiated set: caller falls back
   hipStream_t s = (hipStream_t)stream;
   const int64_t n_tiles = (M + 31) / 32;
-  int blocks = (int)((n_tiles + SHADE_WAVES - 1) / SHADE_WAVES < 256 ? (n_tiles + SHADE_WAVES - 1) / SHADE_WAVES : 256);
-#define DVGO_SHADE(S1, DIFF)                                                                              \
-  shade_fwd_kernel<128, S1, DIFF><<<blocks, SHADE_THREADS, 0, s>>>(feat, C, c_view0, n_view, emb, E, ray_id, M, W1, b1, W2, \
+  const int64_t cap = width == 128 ? 256 : 512;          // width 128: one workgroup per CU (LDS); width 64: two
+  int blocks = (int)((n_tiles + SHADE_WAVES - 1) / SHADE_WAVES < cap ? (n_tiles + SHADE_WAVES - 1) / SHADE_WAVES : cap);
+#define DVGO_SHADE(W, S1, DIFF)                                                                           \
+  shade_fwd_kernel<W, S1, DIFF><<<blocks, SHADE_THREADS, 0, s>>>(feat, C, c_view0, n_view, emb, E, ray_id, M, W1, b1, W2, \
                                                           b2, W3, b3, d_in, rgb, H1, H2, (unsigned long long*)masks, g_shade_experiment)
-  if (d_in <= 36) { if (diffuse) DVGO_SHADE(18, true); else DVGO_SHADE(18, false); }
-  else            { if (diffuse) DVGO_SHADE(20, true); else DVGO_SHADE(20, false); }
+  // S1 = k-steps of layer 1 (2 inputs each, zero-padded): 128-wide head of configs/default.py: d_in 36 / 39;
+  // 64-wide head of configs/llff (lib/dmpigo.py): d_in = 9 + 3
+  if (width == 128) {
+    if (d_in <= 36) { if (diffuse) DVGO_SHADE(128, 18, true); else DVGO_SHADE(128, 18, false); }
+    else            { if (diffuse) DVGO_SHADE(128, 20, true); else DVGO_SHADE(128, 20, false); }
+  } else {
+    if (d_in <= 12) { if (diffuse) DVGO_SHADE(64, 6, true); else DVGO_SHADE(64, 6, false); }
+    else            { if (diffuse) DVGO_SHADE(64, 20, true); else DVGO_SHADE(64, 20, false); }
+  }
 #undef DVGO_SHADE
   DVGO_LAUNCH_CHECK();
   return 0;
@@ -593,16 +608,17 @@ int dvgo_shade_bwd(const float* g_rgb, const float* rgb, const uint64_t* masks, 
   if (!g_rgb || !rgb || !masks || !W1 || !W2 || !W3 || !g_feat || !G1 || !gz) return DVGO_EINVAL;
   const int c_view0 = diffuse ? 3 : 0;
   const int n_view = C - c_view0;
-  if (width != 128 || n_view < 0 || n_view > 32 || d_in < n_view) return DVGO_ERANGE;
+  if ((width != 128 && width != 64) || n_view < 0 || n_view > 32 || d_in < n_view) return DVGO_ERANGE;
   hipStream_t s = (hipStream_t)stream;
   const int64_t n_tiles = (M + 31) / 32;
-  int blocks = (int)((n_tiles + SHADE_WAVES - 1) / SHADE_WAVES < 256 ? (n_tiles + SHADE_WAVES - 1) / SHADE_WAVES : 256);
-  if (diffuse)
-    shade_bwd_kernel<128, true><<<blocks, SHADE_THREADS, 0, s>>>(g_rgb, rgb, (const unsigned long long*)masks, M, W1, W2, W3, d_in, C, c_view0,
-                                                                 n_view, g_feat, G1, gz, g_shade_experiment);
-  else
-    shade_bwd_kernel<128, false><<<blocks, SHADE_THREADS, 0, s>>>(g_rgb, rgb, (const unsigned long long*)masks, M, W1, W2, W3, d_in, C, c_view0,
-                                                                  n_view, g_feat, G1, gz, g_shade_experiment);
+  const int64_t cap = width == 128 ? 256 : 512;
+  int blocks = (int)((n_tiles + SHADE_WAVES - 1) / SHADE_WAVES < cap ? (n_tiles + SHADE_WAVES - 1) / SHADE_WAVES : cap);
+#define DVGO_SHADE_BWD(W, DIFF)                                                                                                       \
+  shade_bwd_kernel<W, DIFF><<<blocks, SHADE_THREADS, 0, s>>>(g_rgb, rgb, (const unsigned long long*)masks, M, W1, W2, W3, d_in, C, c_view0, \
+                                                            n_view, g_feat, G1, gz, g_shade_experiment)
+  if (width == 128) { if (diffuse) DVGO_SHADE_BWD(128, true); else DVGO_SHADE_BWD(128, false); }
+  else              { if (diffuse) DVGO_SHADE_BWD(64, true); else DVGO_SHADE_BWD(64, false); }
+#undef DVGO_SHADE_BWD
   DVGO_LAUNCH_CHECK();
   return 0;
 }
@@ -614,9 +630,13 @@ int dvgo_shade_wgrad(const float* G1, const float* gz, const uint64_t* masks, co
   if (!G1 || !gz || !masks || !W3 || !H1 || !H2 || !feat || !emb || !ray_id || !part || !total) return DVGO_EINVAL;
   const int c_view0 = diffuse ? 3 : 0;
   const int n_view = C - c_view0;
-  if (width != 128 || n_view < 0 || n_view + E > 40) return DVGO_ERANGE;
-  shade_wgrad_kernel<128><<<n_parts, 256, 0, (hipStream_t)stream>>>(
-      G1, gz, (const unsigned int*)masks, W3, H1, H2, feat, C, c_view0, n_view, emb, E, ray_id, M, part);
+  if ((width != 128 && width != 64) || n_view < 0 || n_view + E > 40) return DVGO_ERANGE;
+  if (width == 128)
+    shade_wgrad_kernel<128><<<n_parts, 256, 0, (hipStream_t)stream>>>(
+        G1, gz, (const unsigned int*)masks, W3, H1, H2, feat, C, c_view0, n_view, emb, E, ray_id, M, part);
+  else
+    shade_wgrad_kernel<64><<<n_parts, 128, 0, (hipStream_t)stream>>>(
+        G1, gz, (const unsigned int*)masks, W3, H1, H2, feat, C, c_view0, n_view, emb, E, ray_id, M, part);
   DVGO_LAUNCH_CHECK();
   const int psize = width * width + width * 64 + 32 * width + 3 * width;
   if (hipMemsetAsync(total, 0, (size_t)psize * sizeof(float), (hipStream_t)stream) != hipSuccess) return DVGO_EINVAL;

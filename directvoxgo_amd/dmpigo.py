@@ -13,6 +13,7 @@ import torch.nn.functional as F
 
 from . import render_utils as render_utils_hip
 from .dvgo import make_rgbnet, mlp_forward
+from .shade import shade, viewdir_embed
 from .fused import MarchConfig, composite, composite_depth, fused_march
 from .ops import Alphas2Weights, MaskCache, Raw2Alpha, grid_sample, segment_coo, total_variation_add_grad
 
@@ -23,6 +24,7 @@ class DirectMPIGO(nn.Module):
                  channels_last=True, fused=True, **kwargs):
         super().__init__()
         self.fused, self.channels_last = bool(fused), bool(channels_last)
+        self.fused_shade = True          # fp32-MFMA colour head (csrc/shade.hip) when the rgbnet has a built shape
         xyz_min = torch.as_tensor(np.asarray(xyz_min, dtype=np.float32))
         xyz_max = torch.as_tensor(np.asarray(xyz_max, dtype=np.float32))
         self.register_buffer('xyz_min', xyz_min.clone())
@@ -148,6 +150,10 @@ class DirectMPIGO(nn.Module):
         """lib/dmpigo.py:246-257"""
         if self.rgbnet is None:
             return torch.sigmoid(vox_emb)
+        if self.fused and self.fused_shade and viewdirs.is_cuda and viewdirs.dim() == 2:
+            rgb = shade(self.rgbnet, vox_emb, viewdir_embed(viewdirs, self.viewfreq), ray_id, diffuse=False)
+            if rgb is not None:              # fp32-MFMA colour head (csrc/shade.hip): width 64 / 128, d_in <= 40
+                return rgb
         viewdirs_emb = (viewdirs.unsqueeze(-1) * self.viewfreq).flatten(-2)
         viewdirs_emb = torch.cat([viewdirs, viewdirs_emb.sin(), viewdirs_emb.cos()], -1)[ray_id]
         return torch.sigmoid(mlp_forward(self.rgbnet, torch.cat([vox_emb, viewdirs_emb], -1)))

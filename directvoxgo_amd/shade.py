@@ -3,7 +3,7 @@
 `shade(...)` computes what /root/reference/lib/dvgo.py:516-541 computes with
 `viewdirs_emb[ray_id]`, `torch.cat`, three `nn.Linear`s, two ReLUs and a sigmoid, in one fp32-MFMA
 kernel.  It applies to the reference's default head, Sequential(Linear, ReLU, Sequential(Linear, ReLU),
-Linear) with width 128; other shapes return None and the caller keeps the torch modules.
+Linear) with width 128 or 64; other shapes return None and the caller keeps the torch modules.
 """
 import torch
 import torch.nn as nn
@@ -87,8 +87,10 @@ def head_layers(rgbnet):
         return None
     if not (isinstance(mid, nn.Sequential) and len(mid) == 2 and isinstance(mid[0], nn.Linear) and isinstance(mid[1], nn.ReLU)):
         return None
-    if a.out_features != 128 or mid[0].in_features != 128 or mid[0].out_features != 128 or c.out_features != 3:
-        return None
+    width = a.out_features
+    if width not in (128, 64) or mid[0].in_features != width or mid[0].out_features != width or c.in_features != width \
+            or c.out_features != 3:
+        return None          # built: 128 (configs/default.py) and 64 (configs/llff, lib/dmpigo.py)
     if a.in_features > 40:
         return None
     return a, mid[0], c

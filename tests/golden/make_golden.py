@@ -287,13 +287,14 @@ def gen_forward(R, fine, name, width=32, direct=False):
     save(name, **out)
 
 
-def gen_mpi_forward(R):
-    """Config-4 path: reference DirectMPIGO.forward (lib/dmpigo.py:173-283) incl. K7."""
-    rng = np.random.default_rng(506)
+def gen_mpi_forward(R, width=16, name='forward_mpi'):
+    """Config-4 path: reference DirectMPIGO.forward (lib/dmpigo.py:173-283) incl. K7.
+    `forward_mpi_w64` has the 64-wide head of configs/llff/llff_default.py (the fused colour-head kernels)."""
+    rng = np.random.default_rng(506 + (width if width != 16 else 0))
     mn, mx = np.array([-1.2, -1.0, -1.0], np.float32), np.array([1.2, 1.0, 1.0], np.float32)
     torch.manual_seed(777)
     m = R.dmpigo.DirectMPIGO(mn, mx, num_voxels=12 * 10 * 16, mpi_depth=16, fast_color_thres=1e-3,
-                             rgbnet_dim=9, rgbnet_depth=3, rgbnet_width=16, viewbase_pe=0)
+                             rgbnet_dim=9, rgbnet_depth=3, rgbnet_width=width, viewbase_pe=0)
     with torch.no_grad():
         m.density.add_(torch.from_numpy((rng.standard_normal(m.density.shape) * 2).astype(np.float32)))
         m.k0.copy_(torch.from_numpy((rng.standard_normal(m.k0.shape) * 0.3).astype(np.float32)))
@@ -318,7 +319,7 @@ def gen_mpi_forward(R):
         out['rgbnet_' + k] = v
     for k, v in m.rgbnet.named_parameters():
         out['grad_rgbnet_' + k] = v.grad
-    save('forward_mpi', **out)
+    save(name, **out)
 
 
 def gen_voxel_count_views(R):
@@ -413,6 +414,9 @@ def main():
         if len(sys.argv) > 1 and sys.argv[1] == 'forward_fine_direct':      # add this one fixture only
             gen_forward(R, fine=True, name='forward_fine_direct', width=128, direct=True)
             return
+        if len(sys.argv) > 1 and sys.argv[1] == 'forward_mpi_w64':
+            gen_mpi_forward(R, width=64, name='forward_mpi_w64')
+            return
         gen_constants(R)
         gen_grid_sampler(R)
         gen_sampler_py(R)
@@ -421,6 +425,7 @@ def main():
         gen_forward(R, fine=False, name='forward_coarse')
         gen_forward(R, fine=True, name='forward_fine_direct', width=128, direct=True)
         gen_mpi_forward(R)
+        gen_mpi_forward(R, width=64, name='forward_mpi_w64')
         gen_voxel_count_views(R)
         gen_masked_adam(R)
         gen_trajectory(R)

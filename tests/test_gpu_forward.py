@@ -164,14 +164,16 @@ def test_fused_equals_unfused_on_larger_scene():
 
 
 @pytest.mark.parametrize('fused', [True, False])
-def test_mpi_forward_matches_reference_orchestration(fused):
-    """Config-4 path: DirectMPIGO.forward (lib/dmpigo.py:200-283, K7 sampler) vs the golden fixture."""
+@pytest.mark.parametrize('name', ['forward_mpi', 'forward_mpi_w64'])
+def test_mpi_forward_matches_reference_orchestration(fused, name):
+    """Config-4 path: DirectMPIGO.forward (lib/dmpigo.py:200-283, K7 sampler) vs the golden fixtures
+    (`forward_mpi_w64`: the 64-wide head of configs/llff, which runs on the fused colour-head kernels)."""
     from directvoxgo_amd.dmpigo import DirectMPIGO
-    g = load_golden('forward_mpi')
+    g = load_golden(name)
     nv = int(np.prod(g['world_size'][:2])) * int(g['mpi_depth'])
     m = DirectMPIGO(g['xyz_min'], g['xyz_max'], num_voxels=12 * 10 * 16, mpi_depth=int(g['mpi_depth']),
-                    fast_color_thres=float(g['fast_color_thres']), rgbnet_dim=9, rgbnet_depth=3, rgbnet_width=16,
-                    viewbase_pe=0, fused=fused)
+                    fast_color_thres=float(g['fast_color_thres']), rgbnet_dim=9, rgbnet_depth=3,
+                    rgbnet_width=int(g['rgbnet_0.weight'].shape[0]), viewbase_pe=0, fused=fused)
     assert m.world_size.tolist() == g['world_size'].tolist()
     with torch.no_grad():
         m.density.copy_(torch.from_numpy(g['density'])); m.k0.copy_(torch.from_numpy(g['k0']))

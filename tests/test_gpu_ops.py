@@ -297,15 +297,19 @@ def test_total_variation(ops, oracle, dense):
 
 
 # ------------------------------------------------------------------ N3 fused colour head
-@pytest.mark.parametrize('M,diffuse', [(1, True), (31, True), (1000, False), (70001, True)])
-def test_shade_matches_torch_modules(M, diffuse):
+@pytest.mark.parametrize('M,diffuse,width,C,E', [
+    (1, True, 128, 12, 27), (31, True, 128, 12, 27), (1000, False, 128, 12, 27), (70001, True, 128, 12, 27),
+    (40000, False, 128, 12, 27),                       # the rgbnet_direct head of configs/default.py (d_in 39)
+    (33, False, 64, 9, 3), (50001, False, 64, 9, 3),   # the LLFF head (configs/llff, lib/dmpigo.py): width 64, d_in 12
+    (3000, True, 64, 12, 27), (3000, False, 128, 9, 3)])
+def test_shade_matches_torch_modules(M, diffuse, width, C, E):
     """csrc/shade.hip (fp32 MFMA) vs the torch modules it replaces (lib/dvgo.py:516-541), values and grads."""
     from directvoxgo_amd.dvgo import make_rgbnet
     from directvoxgo_amd.shade import shade
     torch.manual_seed(M)
-    C, E, N = 12, 27, 50
+    N = 50
     d_in = (C - 3 if diffuse else C) + E
-    net = make_rgbnet(d_in, 128, 3).cuda()
+    net = make_rgbnet(d_in, width, 3).cuda()
     feat = torch.randn(M, C, device='cuda', requires_grad=True)
     emb = torch.randn(N, E, device='cuda')
     ray_id = torch.sort(torch.randint(N, (M,), device='cuda'))[0]
@@ -317,16 +321,25 @@ def test_shade_matches_torch_modules(M, diffuse):
     go = torch.randn_like(ref)
     gr = torch.autograd.grad(ref, [feat] + list(net.parameters()), go)
     gs = torch.autograd.grad(rgb, [feat] + list(net.parameters()), go)
-    for a, b in zip(gs, gr):
-        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-4, atol=2e-5 * max(1.0, float(b.abs().max())))
+    # a pre-activation within rounding of zero may land on the other side of the ReLU than in torch's GEMM (different
+    # summation order): that sample's feature gradient then differs as a whole row -- allow a handful of such rows
+    a, b = gs[0].cpu().numpy(), gr[0].cpu().numpy()
+    bad_rows = (~np.isclose(a, b, rtol=2e-4, atol=2e-5 * max(1.0, float(np.abs(b).max())))).any(1)
+    assert bad_rows.sum() <= max(1, M // 10000), f'{bad_rows.sum()} rows of the feature gradient differ'
+    for a, b in zip(gs[1:], gr[1:]):
+        a, b = a.cpu().numpy(), b.cpu().numpy()
+        if bad_rows.sum() == 0:
+            np.testing.assert_allclose(a, b, rtol=2e-4, atol=2e-5 * max(1.0, float(np.abs(b).max())))
+        else:       # the flipped sample(s) enter every weight gradient with a whole-sample contribution
+            assert np.linalg.norm(a - b) <= 2e-2 * np.linalg.norm(b)
 
 
 def test_shade_falls_back_for_other_heads():
     from directvoxgo_amd.dvgo import make_rgbnet
     from directvoxgo_amd.shade import shade
-    net = make_rgbnet(36, 64, 3).cuda()
-    assert shade(net, torch.randn(5, 12, device='cuda'), torch.randn(2, 27, device='cuda'),
-                 torch.zeros(5, dtype=torch.int64, device='cuda'), True) is None
+    for net in (make_rgbnet(36, 96, 3), make_rgbnet(36, 128, 4), make_rgbnet(36, 256, 3)):
+        assert shade(net.cuda(), torch.randn(5, 12, device='cuda'), torch.randn(2, 27, device='cuda'),
+                     torch.zeros(5, dtype=torch.int64, device='cuda'), True) is None
 
 
 # ------------------------------------------------------------------ H3 glue kernels
