@@ -76,6 +76,41 @@ tv_kernel(const float* __restrict__ param, float* __restrict__ grad, float wy, f
   grad[o] += g;
 }
 
+// Row form of the same stencil for the two dense layouts (channels-last: a row = the K*C contiguous floats of one
+// (i, j); channel-first: the K floats of one (c, i, j)).  One workgroup per row: the (c, i, j) decomposition and the
+// j / i boundary tests are wave-uniform scalars, the k boundary is `e < sK` / `e >= R - sK`, so a thread does no
+// integer division at all (the flat kernel spends ~300 instructions per element on 64-bit div/mod: 1.34 ms per
+// step on the config-4 grids, 4x the traffic bound), and all seven accesses are contiguous across the wave.
+template <bool DENSE>
+__global__ void __launch_bounds__(DVGO_BLOCK)
+tv_rows_kernel(const float* __restrict__ param, float* __restrict__ grad, float wy, float wz, int R, int sK,
+               int I, int J, int64_t sC, int64_t sI, int64_t sJ) {
+  const int row = blockIdx.x;
+  const int ij = I * J;
+  const int c = row / ij, rem = row - c * ij;
+  const int i = rem / J, j = rem - i * J;
+  const int64_t base = c * sC + i * sI + j * sJ;
+  const float wjm = (j == 0) ? 0.f : wy, wjp = (j == J - 1) ? 0.f : wy;
+  const float wim = (i == 0) ? 0.f : wz, wip = (i == I - 1) ? 0.f : wz;      // i axis weighted by wz (reference quirk)
+  const int64_t ojm = (j == 0) ? 0 : -sJ, ojp = (j == J - 1) ? 0 : sJ;       // clamped: the loads stay in bounds
+  const int64_t oim = (i == 0) ? 0 : -sI, oip = (i == I - 1) ? 0 : sI;
+  const float* pr = param + base;
+  float* gr = grad + base;
+  for (int e = threadIdx.x; e < R; e += blockDim.x) {
+    const float g0 = gr[e];
+    if (!DENSE && g0 == 0.0f) continue;
+    const float p = pr[e];
+    float g = 0.f;
+    g += (e < sK      ? 0.f : wz * clamp1(p - pr[e - sK]));
+    g += (e >= R - sK ? 0.f : wz * clamp1(p - pr[e + sK]));
+    g += wjm * clamp1(p - pr[e + ojm]);
+    g += wjp * clamp1(p - pr[e + ojp]);
+    g += wim * clamp1(p - pr[e + oim]);
+    g += wip * clamp1(p - pr[e + oip]);
+    gr[e] = g0 + g;
+  }
+}
+
 extern "C" {
 
 int dvgo_adam_upd(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
@@ -113,6 +148,20 @@ int dvgo_total_variation_add_grad(const float* param, float* grad, float wx, flo
   wy /= 6; wz /= 6;   // total_variation_kernel.cu:46-48
   const bool cl = (sC == 1 && C > 1);
   hipStream_t s = (hipStream_t)stream;
+  // dense layouts: channels-last (sC == 1, sK == C) or channel-first (sK == 1), any C
+  const bool rows_cl = (sC == 1 && sK == C && sJ == sz_k * C && sI == sz_j * sz_k * C);
+  const bool rows_cf = (sK == 1 && sJ == sz_k && sI == sz_j * sz_k && (C == 1 || sC == sz_i * sz_j * sz_k));
+  const int64_t n_rows = rows_cl ? sz_i * sz_j : C * sz_i * sz_j;
+  const int64_t R = rows_cl ? sz_k * C : sz_k;
+  if ((rows_cl || rows_cf) && n_rows < ((int64_t)1 << 31) && R < ((int64_t)1 << 30)) {
+    const int threads = R >= 256 ? 256 : (R > 128 ? 256 : (R > 64 ? 128 : 64));
+    if (dense_mode)
+      tv_rows_kernel<true><<<(int)n_rows, threads, 0, s>>>(param, grad, wy, wz, (int)R, (int)sK, (int)sz_i, (int)sz_j, sC, sI, sJ);
+    else
+      tv_rows_kernel<false><<<(int)n_rows, threads, 0, s>>>(param, grad, wy, wz, (int)R, (int)sK, (int)sz_i, (int)sz_j, sC, sI, sJ);
+    DVGO_LAUNCH_CHECK();
+    return 0;
+  }
   if (dense_mode)
     tv_kernel<true><<<dvgo_blocks(N, DVGO_BLOCK), DVGO_BLOCK, 0, s>>>(param, grad, wy, wz, C, sz_i, sz_j, sz_k, sC, sI, sJ, sK, cl, N);
   else

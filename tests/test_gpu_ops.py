@@ -281,10 +281,11 @@ def test_adam_kernels_vs_fixture(oracle):
         np.testing.assert_allclose(opt.state[p]['exp_avg'].cpu().numpy(), g[f'{tag}_exp_avg'], rtol=1e-6, atol=1e-9)
 
 
+@pytest.mark.parametrize('shape', [(1, 12, 9, 10, 11), (1, 1, 7, 5, 300), (1, 9, 3, 4, 70)])
 @pytest.mark.parametrize('dense', [True, False])
-def test_total_variation(ops, oracle, dense):
+def test_total_variation(ops, oracle, dense, shape):
     rng = np.random.default_rng(80)
-    p = (rng.standard_normal((1, 12, 9, 10, 11)) * 2).astype(np.float32)
+    p = (rng.standard_normal(shape) * 2).astype(np.float32)
     grad = rng.standard_normal(p.shape).astype(np.float32)
     grad[rng.random(p.shape) < 0.6] = 0
     exp = grad.copy()
