@@ -122,8 +122,12 @@ class TrainStep:
     """One optimisation step on one batch of rays; ``world_size > 1`` shards the batch by rank."""
 
     def __init__(self, model, cfg_train, render_kwargs, optimizer=None, process_group=None, fused_loss=True,
-                 overlap_wgrad=True):
+                 overlap_wgrad=True, touched_reduce=True):
         self.model = model
+        # data parallel, sparse scenes: all-reduce only the voxels some rank touched (see _reduce_touched)
+        self.touched_reduce = touched_reduce
+        self._touched_frac = None            # fraction of voxels in the last union; None: not probed yet
+        self._steps_since_probe = 0
         self.overlap_wgrad = overlap_wgrad    # colour-head weight gradients on a second stream (shade.defer_wgrad)
         self.fused_loss = fused_loss
         self.cfg = cfg_train
@@ -140,6 +144,14 @@ class TrainStep:
         works = []
         if self.world == 1:
             return works
+        if self.touched_reduce:
+            self._steps_since_probe += 1
+            probe = self._touched_frac is None or self._steps_since_probe >= self.PROBE_EVERY
+            if probe or self._touched_frac <= self.TOUCHED_MAX:
+                rd = self._rows()
+                pending = self._reduce_touched(*rd) if rd is not None else None
+                if pending is not None:
+                    return [pending]
         for p in (self.model.density, self.model.k0):
             if p.grad is not None:
                 flat = flat_view(p.grad)
@@ -150,6 +162,50 @@ class TrainStep:
                     dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=self.pg)
                     p.grad.copy_(tmp)
         return works
+
+    # A batch of rays touches the voxels along those rays only: on a trained scene a few per cent of the grid, while
+    # the dense all-reduce always moves all of it (213 MB at 160^3 -- more than a whole step of compute on such
+    # scenes).  The touched set differs per rank, so: OR-reduce a byte mask (4 MB), compact the union's rows
+    # [n, C + 1] (features + density), all-reduce that, write back.  Untouched voxels stay exactly zero on every
+    # rank, which is what the masked Adam and the sparse TV branch on.  Used while the union stays below
+    # TOUCHED_MAX of the grid (decided from the previous union, identical on all ranks; re-probed every
+    # PROBE_EVERY steps while the dense path is in use).
+    TOUCHED_MAX = 0.35
+    PROBE_EVERY = 64
+
+    def _rows(self):
+        """(k0.grad as [n_vox, C] rows, density.grad as [n_vox]) when both share the lattice and are row-addressable."""
+        d, k = self.model.density.grad, self.model.k0.grad
+        if d is None or k is None or d.dim() != 5 or k.dim() != 5 or d.shape[2:] != k.shape[2:] or not d.is_contiguous():
+            return None
+        flat = flat_view(k) if k.is_contiguous(memory_format=torch.channels_last_3d) else None
+        if flat is None:
+            return None
+        return flat.view(-1, k.shape[1]), d.view(-1)
+
+    def _reduce_touched(self, rows, dflat):
+        mask = (rows != 0).any(1) | (dflat != 0)
+        m8 = mask.to(torch.uint8)
+        dist.all_reduce(m8, op=dist.ReduceOp.MAX, group=self.pg)
+        idx = m8.nonzero().flatten()                       # the union, identical on every rank (one host read)
+        self._touched_frac = idx.numel() / max(m8.numel(), 1)
+        self._steps_since_probe = 0
+        if self._touched_frac > self.TOUCHED_MAX:
+            return None                                     # dense scene: the caller falls back to the plain all-reduce
+        C = rows.shape[1]
+        compact = torch.empty((idx.numel(), C + 1), dtype=rows.dtype, device=rows.device)
+        if idx.numel():
+            compact[:, :C] = rows[idx]
+            compact[:, C] = dflat[idx]
+        work = dist.all_reduce(compact, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+
+        class _Pending:
+            def wait(_self):
+                work.wait()
+                if idx.numel():
+                    rows[idx] = compact[:, :C]
+                    dflat[idx] = compact[:, C]
+        return _Pending()
 
     def reduce_small(self):
         """One flat bucket for the handful of MLP gradients."""

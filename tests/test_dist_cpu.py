@@ -56,10 +56,14 @@ def make_batch(n):
     return ro, rd, rd / rd.norm(dim=-1, keepdim=True), torch.rand(n, 3, generator=g)
 
 
-def run_steps(model, batch, rank, world, n_steps=3):
+def run_steps(model, batch, rank, world, n_steps=3, mode='dense'):
     cfg = dict(FINE_TRAIN, weight_entropy_last=0.01, weight_rgbper=0.05)
     opt = torch.optim.SGD(model.parameters(), lr=0.5)
-    step = TrainStep(model, cfg, dict(bg=1), optimizer=opt)
+    step = TrainStep(model, cfg, dict(bg=1), optimizer=opt, touched_reduce=(mode != 'dense'))
+    if mode == 'touched':
+        step.TOUCHED_MAX = 2.0            # always take the compact (touched-voxel) reduction
+    elif mode == 'adaptive':
+        step.TOUCHED_MAX = 0.0            # probe, find the union too large, fall back to the dense all-reduce
     n = batch[0].shape[0] // world
     shard = tuple(t[rank * n:(rank + 1) * n] for t in batch)
     losses = []
@@ -68,13 +72,13 @@ def run_steps(model, batch, rank, world, n_steps=3):
     return torch.stack(losses)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, mode='dense'):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     torch.set_num_threads(1)
     model = ToyModel()
-    losses = run_steps(model, make_batch(32), rank, world)
+    losses = run_steps(model, make_batch(32), rank, world, mode=mode)
     dist.all_reduce(losses)           # per-rank shares of the global loss add up to it
     if rank == 0:
         # numpy: pickled by value (torch tensors would travel as shared-memory handles of a process about to exit)
@@ -92,13 +96,15 @@ def _free_port():
 
 
 @pytest.mark.timeout(120)
-def test_two_ranks_equal_one_process():
+@pytest.mark.parametrize('mode', ['dense', 'touched', 'adaptive'])
+def test_two_ranks_equal_one_process(mode):
+    """`touched`: the grid gradients travel as the compacted union of the voxels either rank touched."""
     ref_model = ToyModel()
     ref_losses = run_steps(ref_model, make_batch(32), 0, 1)
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, mode)) for r in range(2)]
     for p in procs:
         p.start()
     sd, losses = q.get(timeout=100)
