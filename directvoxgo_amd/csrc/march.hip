@@ -205,8 +205,8 @@ march_hit_kernel(const float* __restrict__ rays_start, const float* __restrict__
 // ----------------------------------------------------------------------------------
 // march_gather: flat over M3.  C4 = C/4 channel vectors when the grid is channels-last.
 // ----------------------------------------------------------------------------------
-template <int CVEC>   // CVEC > 0: channels-last, C == 4*CVEC, 16-B aligned ; 0: generic strides
-__global__ void __launch_bounds__(DVGO_BLOCK)
+template <int CVEC, int CS = 0>   // CVEC > 0: channels-last, C == 4*CVEC, 16-B aligned; CS > 0: channels-last, C == CS, dword
+__global__ void __launch_bounds__(DVGO_BLOCK)   // loads (rows of 3 / 9 floats: coarse stage, LLFF); both 0: generic strides
 march_gather_kernel(const dvgo_rec3_t* __restrict__ rec3, const int64_t* __restrict__ n_steps,
                     const int64_t* __restrict__ cum, int64_t rec_stride, const int64_t* __restrict__ off3,
                     int64_t n_rays, int64_t M3, const float* __restrict__ rays_start, const float* __restrict__ rays_dir,
@@ -256,6 +256,20 @@ march_gather_kernel(const dvgo_rec3_t* __restrict__ rec3, const int64_t* __restr
     float4* o = reinterpret_cast<float4*>(feat + i * (int64_t)(4 * CVEC));
 #pragma unroll
     for (int c = 0; c < CVEC; ++c) o[c] = acc[c];
+  } else if (CS > 0) {
+    float acc[CS > 0 ? CS : 1];
+#pragma unroll
+    for (int c = 0; c < CS; ++c) acc[c] = 0.f;
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+      if (ok[n]) {
+        const float* p = k0 + off[n];
+#pragma unroll
+        for (int c = 0; c < CS; ++c) acc[c] = fmaf(p[c], w[n], acc[c]);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CS; ++c) feat[i * CS + c] = acc[c];
   } else {
     for (int c = 0; c < C; ++c) {
       float acc = 0.f;
@@ -417,15 +431,22 @@ march_feat_bwd_dedup_kernel(const float* __restrict__ grad_feat, const float* __
       float px, py, pz;
       march_pos(rays_start, rays_dir, ray_id[i], P.stepdist, (int)step_id[i], px, py, pz);
       const TriSetup t = dvgo_tri_setup(px, py, pz, P.mnx, P.mny, P.mnz, P.mxx, P.mxy, P.mxz, P.X, P.Y, P.Z);
-      const float4* gp = reinterpret_cast<const float4*>(grad_feat + i * C);
-      float4 gv[C / 4];
+      float gs[C];                       // this sample's gradient row (16-B loads when the row allows it)
+      if constexpr (C % 4 == 0) {
+        const float4* gp = reinterpret_cast<const float4*>(grad_feat + i * C);
 #pragma unroll
-      for (int c = 0; c < C / 4; ++c) gv[c] = gp[c];
+        for (int c = 0; c < C / 4; ++c) {
+          const float4 v = gp[c];
+          gs[4 * c] = v.x; gs[4 * c + 1] = v.y; gs[4 * c + 2] = v.z; gs[4 * c + 3] = v.w;
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < C; ++c) gs[c] = grad_feat[i * C + c];
+      }
       const float ge = EXTRA ? grad_extra[i] : 0.0f;
       if (half == 0) {
-        float4* dst = reinterpret_cast<float4*>(&L.g[sl][0]);
 #pragma unroll
-        for (int c = 0; c < C / 4; ++c) dst[c] = gv[c];
+        for (int c = 0; c < C; ++c) L.g[sl][c] = gs[c];
         if (EXTRA) L.g[sl][C] = ge;
       }
 #pragma unroll
@@ -448,7 +469,6 @@ march_feat_bwd_dedup_kernel(const float* __restrict__ grad_feat, const float* __
           wq[q] = w;
         } else {
           float* dst = grad_k0 + (int64_t)key * RS;
-          const float* gs = reinterpret_cast<const float*>(gv);
 #pragma unroll
           for (int c = 0; c < C; ++c) atomicAdd(dst + c, w * gs[c]);
           if (EXTRA) atomicAdd(dst + C, w * ge);
@@ -708,6 +728,12 @@ int dvgo_march_gather(const dvgo_rec3_t* rec3, const int64_t* n_steps, const int
   else if (vec && C == 4) DVGO_GATHER(1);
   else if (vec && C == 8) DVGO_GATHER(2);
   else if (vec && C == 16) DVGO_GATHER(4);
+  else if (sC == 1 && C == 9)
+    march_gather_kernel<0, 9><<<blocks, DVGO_BLOCK, 0, s>>>(rec3, n_steps, n_steps_cumsum, rec_stride, off3, n_rays, M3, rays_start,
+        rays_dir, P, k0, C, sC, sX, sY, sZ, ray_id, step_id, weights, alpha, feat);
+  else if (sC == 1 && C == 3)
+    march_gather_kernel<0, 3><<<blocks, DVGO_BLOCK, 0, s>>>(rec3, n_steps, n_steps_cumsum, rec_stride, off3, n_rays, M3, rays_start,
+        rays_dir, P, k0, C, sC, sX, sY, sZ, ray_id, step_id, weights, alpha, feat);
   else DVGO_GATHER(0);
 #undef DVGO_GATHER
   DVGO_LAUNCH_CHECK();
@@ -757,7 +783,7 @@ int dvgo_march_feat_bwd(const float* grad_feat, const float* grad_extra, const i
   // voxel-major rows of RS = sZ floats (RS == C: the channels-last gradient itself; RS == 16: 64-byte rows of a
   // combined gradient buffer)
   const bool rows = (sC == 1) && (sZ >= C) && (sY == (int64_t)Z * sZ) && (sX == (int64_t)Y * Z * sZ) &&
-                    ((int64_t)X * Y * Z < ((int64_t)1 << 31)) && ((((uintptr_t)grad_feat) & 15) == 0);
+                    ((int64_t)X * Y * Z < ((int64_t)1 << 31)) && ((C % 4 != 0) || ((((uintptr_t)grad_feat) & 15) == 0));
   const int RS = (int)sZ;
   const int64_t n_pass = (M3 + 31) / 32;
   const int blocks = (int)((n_pass + 3) / 4 < 4096 ? (n_pass + 3) / 4 : 4096);
@@ -767,10 +793,12 @@ int dvgo_march_feat_bwd(const float* grad_feat, const float* grad_extra, const i
   if (grad_extra != nullptr) {      // the extra channel is only built for the 12-feature, row-layout case
     if (!(rows && C == 12 && sZ >= C + 1)) return DVGO_ERANGE;
     DVGO_FEAT_BWD(12, true);
-  } else if (variant == 1 && rows && (C == 12 || C == 4 || C == 8 || C == 16)) {
+  } else if (variant == 1 && rows && (C == 12 || C == 4 || C == 8 || C == 16 || C == 9 || C == 3)) {
     if (C == 12) DVGO_FEAT_BWD(12, false);
     else if (C == 4) DVGO_FEAT_BWD(4, false);
     else if (C == 8) DVGO_FEAT_BWD(8, false);
+    else if (C == 9) DVGO_FEAT_BWD(9, false);         // LLFF (lib/dmpigo.py, rgbnet_dim 9)
+    else if (C == 3) DVGO_FEAT_BWD(3, false);         // coarse stage (k0 = RGB)
     else DVGO_FEAT_BWD(16, false);
   } else {
     march_feat_bwd_kernel<<<dvgo_blocks(M3 * C, DVGO_BLOCK), DVGO_BLOCK, 0, s>>>(
