@@ -62,7 +62,27 @@ def ptr(t):
 
 
 def stream_of(t):
-    return _vp(torch.cuda.current_stream(t.device).cuda_stream)
+    """torch's current stream on t's device as a raw hipStream_t (the C-level getter: a Stream object per launch costs
+    more host time than the launch itself on small batches)."""
+    return _vp(torch._C._cuda_getCurrentRawStream(t.device.index))
+
+
+class _NoCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NOCTX = _NoCtx()
+
+
+def device_of(t):
+    """`torch.cuda.device_of(t)`, free when t already lives on the current device (the usual one-process-per-GPU case)."""
+    if t.device.index == torch.cuda.current_device():
+        return _NOCTX
+    return torch.cuda.device_of(t)
 
 
 _ERR = {-1: 'invalid argument', -2: 'size exceeds 32-bit launch range'}

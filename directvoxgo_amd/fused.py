@@ -99,7 +99,7 @@ class _FusedMarch(torch.autograd.Function):
         n3 = torch.empty(N, dtype=torch.int32, device=dev)
         last = torch.empty(N, dtype=torch.float32, device=dev)
         off3 = torch.empty(N + 1, dtype=torch.int64, device=dev)
-        with torch.cuda.device_of(rays_o):
+        with L.device_of(rays_o):
             if not ndc:
                 L.call('dvgo_sample_pts_prepare', ptr(rays_o), ptr(rays_d), ptr(cfg.xyz_min_t), ptr(cfg.xyz_max_t),
                        _flt(cfg.near), _flt(cfg.far), _flt(cfg.stepdist), _i64(N), ptr(t_min), ptr(t_max),
@@ -148,7 +148,7 @@ class _FusedMarch(torch.autograd.Function):
         st = stream_of(start)
         grad_density = grad_k0 = None
         dev = start.device
-        with torch.cuda.device_of(start):
+        with L.device_of(start):
             want_k0 = ctx.needs_input_grad[1] and g_feat is not None and C > 0
             want_d = ctx.needs_input_grad[0]
             gw = gl = None
@@ -207,7 +207,7 @@ def fused_hit(rays_o, rays_d, cfg):
     dirs = torch.empty((N, 3), dtype=torch.float32, device=dev)
     hit = torch.empty(N, dtype=torch.bool, device=dev)
     mask = cfg.mask
-    with torch.cuda.device_of(rays_o):
+    with L.device_of(rays_o):
         st = stream_of(rays_o)
         L.call('dvgo_sample_pts_prepare', ptr(rays_o), ptr(rays_d), ptr(cfg.xyz_min_t), ptr(cfg.xyz_max_t), _flt(cfg.near),
                _flt(cfg.far), _flt(cfg.stepdist), _i64(N), ptr(t_min), ptr(t_max), ptr(n_steps), ptr(None), ptr(start),
@@ -231,7 +231,7 @@ class _Composite(torch.autograd.Function):
         rgb = rgb.contiguous()
         weights = weights.contiguous()
         out = torch.empty((N, 3), dtype=torch.float32, device=weights.device)
-        with torch.cuda.device_of(weights):
+        with L.device_of(weights):
             L.call('dvgo_march_composite', ptr(weights), ptr(rgb), ptr(None), ptr(off3), _i64(N),
                    ptr(alphainv_last.contiguous()), _flt(float(bg)), ptr(out), ptr(None), stream_of(weights))
         ctx.save_for_backward(weights, rgb, ray_id)
@@ -247,10 +247,10 @@ class _Composite(torch.autograd.Function):
         M3 = weights.shape[0]
         gw = torch.empty_like(weights) if ctx.needs_input_grad[0] else None
         grgb = torch.empty_like(rgb) if ctx.needs_input_grad[1] else None
-        with torch.cuda.device_of(weights):
+        glast = torch.empty(ctx.N, dtype=torch.float32, device=g.device) if ctx.needs_input_grad[2] else None
+        with L.device_of(weights):
             L.call('dvgo_march_composite_bwd', ptr(g), ptr(weights), ptr(rgb), ptr(ray_id), _i64(M3), _i64(ctx.N),
-                   _flt(ctx.bg), ptr(gw), ptr(grgb), ptr(None), stream_of(weights))
-        glast = g.sum(-1) * ctx.bg if ctx.needs_input_grad[2] else None
+                   _flt(ctx.bg), ptr(gw), ptr(grgb), ptr(glast), stream_of(weights))
         return gw, grgb, glast, None, None, None
 
 
@@ -267,7 +267,7 @@ def composite_depth(weights, step_id, off3, n_rays):
     zeros = torch.zeros(n_rays, dtype=torch.float32, device=dev)
     out = torch.empty((n_rays, 3), dtype=torch.float32, device=dev)
     depth = torch.empty(n_rays, dtype=torch.float32, device=dev)
-    with torch.cuda.device_of(weights):
+    with L.device_of(weights):
         L.call('dvgo_march_composite', ptr(weights.contiguous()), ptr(dummy_rgb), ptr(step_id), ptr(off3),
                _i64(n_rays), ptr(zeros), _flt(0.0), ptr(out), ptr(depth), stream_of(weights))
     return depth

@@ -34,7 +34,7 @@ def adam_upd(param, grad, exp_avg, exp_avg_sq, step, beta1, beta2, lr, eps, mode
     if not _dense_same_layout(*ts):
         raise RuntimeError('param, grad and optimizer state must share one memory layout')
     n = param.numel()
-    with torch.cuda.device_of(param):
+    with L.device_of(param):
         L.call('dvgo_adam_upd', ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), ptr(perlr if mode == 2 else None),
                _i64(n), _flt(adam_step_size(lr, beta1, beta2, step)), _flt(beta1), _flt(beta2), _flt(eps), _int(mode),
                stream_of(param))
@@ -51,7 +51,7 @@ def adam_upd_multi(items, step, beta1, beta2, lr, eps):
     vs = PT(*[st['exp_avg_sq'].data_ptr() for _, st in items])
     ne = (ctypes.c_int64 * n)(*[p.numel() for p, _ in items])
     p0 = items[0][0]
-    with torch.cuda.device_of(p0):
+    with L.device_of(p0):
         L.call('dvgo_adam_upd_multi', ps, gs, ms, vs, ne, _int(n), _flt(adam_step_size(lr, beta1, beta2, step)), _flt(beta1),
                _flt(beta2), _flt(eps), stream_of(p0))
 

@@ -77,7 +77,7 @@ class _GridSample(torch.autograd.Function):
         C, X, Y, Z, sC, sX, sY, sZ = _grid_geom(grid)
         M = xyz.shape[0]
         out = torch.empty((M, C), dtype=torch.float32, device=xyz.device)
-        with torch.cuda.device_of(xyz):
+        with L.device_of(xyz):
             L.call('dvgo_grid_sample_fwd', ptr(grid), _int(C), _int(X), _int(Y), _int(Z), _i64(sC), _i64(sX),
                    _i64(sY), _i64(sZ), ptr(xyz), ptr(xyz_min), ptr(xyz_max), _i64(M), ptr(out), stream_of(xyz))
         ctx.save_for_backward(xyz, xyz_min, xyz_max)
@@ -96,7 +96,7 @@ class _GridSample(torch.autograd.Function):
             # zero-filled, same strides as the parameter (F.grid_sample's backward does the same)
             grad_grid = torch.zeros_like(ctx.grid_meta, memory_format=torch.preserve_format)
             assert grad_grid.stride() == ctx.grid_meta.stride()
-            with torch.cuda.device_of(xyz):
+            with L.device_of(xyz):
                 L.call('dvgo_grid_sample_bwd', ptr(grad_out), _int(C), _int(X), _int(Y), _int(Z), _i64(sC),
                        _i64(sX), _i64(sY), _i64(sZ), ptr(xyz), ptr(xyz_min), ptr(xyz_max), _i64(xyz.shape[0]),
                        ptr(grad_grid), stream_of(xyz))
@@ -207,7 +207,7 @@ class _SegmentSum(torch.autograd.Function):
         squeeze = src.dim() == 1
         C = 1 if squeeze else src.shape[1]
         res = out.clone().contiguous()
-        with torch.cuda.device_of(src):
+        with L.device_of(src):
             L.call('dvgo_segment_sum', ptr(src), ptr(index), _i64(src.shape[0]), _int(C), _i64(res.shape[0]),
                    ptr(res), stream_of(src))
         ctx.save_for_backward(index)
@@ -236,7 +236,7 @@ def total_variation_add_grad(param, grad, wx, wy, wz, dense_mode):
     if param.stride() != grad.stride():
         raise RuntimeError('param and grad must share strides')
     C, X, Y, Z, sC, sX, sY, sZ = _grid_geom(param)
-    with torch.cuda.device_of(param):
+    with L.device_of(param):
         L.call('dvgo_total_variation_add_grad', ptr(param), ptr(grad), _flt(float(wx)), _flt(float(wy)),
                _flt(float(wz)), _i64(C), _i64(X), _i64(Y), _i64(Z), _i64(sC), _i64(sX), _i64(sY), _i64(sZ),
                _int(1 if dense_mode else 0), stream_of(param))

@@ -24,7 +24,7 @@ def infer_t_minmax(rays_o, rays_d, xyz_min, xyz_max, near, far):
     n = rays_o.shape[0]
     t_min = torch.empty(n, dtype=torch.float32, device=rays_o.device)
     t_max = torch.empty_like(t_min)
-    with torch.cuda.device_of(rays_o):
+    with L.device_of(rays_o):
         L.call('dvgo_infer_t_minmax', ptr(rays_o), ptr(rays_d), ptr(xyz_min), ptr(xyz_max), _f(near), _f(far),
                _i64(n), ptr(t_min), ptr(t_max), stream_of(rays_o))
     return [t_min, t_max]
@@ -36,7 +36,7 @@ def infer_n_samples(t_min, t_max, stepdist):
         check_input(x, n); check_f32(x, n)
     n = t_min.shape[0]
     out = torch.empty(n, dtype=torch.int64, device=t_min.device)
-    with torch.cuda.device_of(t_min):
+    with L.device_of(t_min):
         L.call('dvgo_infer_n_samples', ptr(t_min), ptr(t_max), _f(stepdist), _i64(n), ptr(out), stream_of(t_min))
     return out
 
@@ -48,7 +48,7 @@ def infer_ray_start_dir(rays_o, rays_d, t_min):
     n = rays_o.shape[0]
     start = torch.empty_like(rays_o)
     dirs = torch.empty_like(rays_o)
-    with torch.cuda.device_of(rays_o):
+    with L.device_of(rays_o):
         L.call('dvgo_infer_ray_start_dir', ptr(rays_o), ptr(rays_d), ptr(t_min), _i64(n), ptr(start), ptr(dirs),
                stream_of(rays_o))
     return [start, dirs]
@@ -64,7 +64,7 @@ def _prepare(rays_o, rays_d, xyz_min, xyz_max, near, far, stepdist):
     cum = torch.empty(n, dtype=torch.int64, device=dev)
     start = torch.empty((n, 3), dtype=torch.float32, device=dev)
     dirs = torch.empty((n, 3), dtype=torch.float32, device=dev)
-    with torch.cuda.device_of(rays_o):
+    with L.device_of(rays_o):
         L.call('dvgo_sample_pts_prepare', ptr(rays_o), ptr(rays_d), ptr(xyz_min), ptr(xyz_max), _f(near), _f(far),
                _f(stepdist), _i64(n), ptr(t_min), ptr(t_max), ptr(n_steps), ptr(cum), ptr(start), ptr(dirs),
                stream_of(rays_o))
@@ -88,7 +88,7 @@ def sample_pts_on_rays(rays_o, rays_d, xyz_min, xyz_max, near, far, stepdist):
     mask = torch.empty(total, dtype=torch.bool, device=dev)
     ray_id = torch.empty(total, dtype=torch.int64, device=dev)
     step_id = torch.empty(total, dtype=torch.int64, device=dev)
-    with torch.cuda.device_of(rays_o):
+    with L.device_of(rays_o):
         L.call('dvgo_sample_pts_fill', ptr(start), ptr(dirs), ptr(xyz_min), ptr(xyz_max), ptr(cum), _i64(n),
                _f(stepdist), _i64(total), ptr(pts), ptr(mask), ptr(ray_id), ptr(step_id), stream_of(rays_o))
     return [pts, mask, ray_id, step_id, n_steps, t_min, t_max]
@@ -103,7 +103,7 @@ def sample_ndc_pts_on_rays(rays_o, rays_d, xyz_min, xyz_max, N_samples):
     S = int(N_samples)
     pts = torch.empty((n, S, 3), dtype=torch.float32, device=rays_o.device)
     mask = torch.empty((n, S), dtype=torch.bool, device=rays_o.device)
-    with torch.cuda.device_of(rays_o):
+    with L.device_of(rays_o):
         L.call('dvgo_sample_ndc_pts_on_rays', ptr(rays_o), ptr(rays_d), ptr(xyz_min), ptr(xyz_max), _int(S), _i64(n),
                ptr(pts), ptr(mask), stream_of(rays_o))
     return [pts, mask]
@@ -119,7 +119,7 @@ def maskcache_lookup(world, xyz, xyz2ijk_scale, xyz2ijk_shift):
     assert world.dim() == 3 and xyz.dim() == 2 and xyz.shape[1] == 3
     n = xyz.shape[0]
     out = torch.empty(n, dtype=torch.bool, device=xyz.device)
-    with torch.cuda.device_of(xyz):
+    with L.device_of(xyz):
         L.call('dvgo_maskcache_lookup', ptr(world), ptr(xyz), ptr(xyz2ijk_scale), ptr(xyz2ijk_shift),
                _int(world.shape[0]), _int(world.shape[1]), _int(world.shape[2]), _i64(n), ptr(out), stream_of(xyz))
     return out
@@ -131,7 +131,7 @@ def raw2alpha(density, shift, interval):
     assert density.dim() == 1
     e = torch.empty_like(density)
     a = torch.empty_like(density)
-    with torch.cuda.device_of(density):
+    with L.device_of(density):
         L.call('dvgo_raw2alpha', ptr(density), _f(shift), _f(interval), _i64(density.shape[0]), ptr(e), ptr(a),
                stream_of(density))
     return [e, a]
@@ -142,7 +142,7 @@ def raw2alpha_backward(exp, grad_back, interval):
     check_input(exp, 'exp'); check_input(grad_back, 'grad_back')
     check_f32(exp, 'exp'); check_f32(grad_back, 'grad_back')
     g = torch.empty_like(exp)
-    with torch.cuda.device_of(exp):
+    with L.device_of(exp):
         L.call('dvgo_raw2alpha_backward', ptr(exp), ptr(grad_back), _f(interval), _i64(exp.shape[0]), ptr(g),
                stream_of(exp))
     return g
@@ -162,7 +162,7 @@ def alpha2weight(alpha, ray_id, n_rays):
     last = torch.empty(n_rays, dtype=torch.float32, device=dev)
     i_start = torch.empty(n_rays, dtype=torch.int64, device=dev)
     i_end = torch.empty(n_rays, dtype=torch.int64, device=dev)
-    with torch.cuda.device_of(alpha):
+    with L.device_of(alpha):
         L.call('dvgo_alpha2weight', ptr(alpha), ptr(ray_id), _i64(m), _i64(n_rays), ptr(w), ptr(T), ptr(last),
                ptr(i_start), ptr(i_end), stream_of(alpha))
     return [w, T, last, i_start, i_end]
@@ -174,7 +174,7 @@ def alpha2weight_backward(alpha, weight, T, alphainv_last, i_start, i_end, n_ray
                  (i_start, 'i_start'), (i_end, 'i_end'), (grad_weights, 'grad_weights'), (grad_last, 'grad_last')):
         check_input(x, n)
     g = torch.empty_like(alpha)
-    with torch.cuda.device_of(alpha):
+    with L.device_of(alpha):
         L.call('dvgo_alpha2weight_backward', ptr(alpha), ptr(weight), ptr(T), ptr(alphainv_last), ptr(i_start),
                ptr(i_end), _i64(int(n_rays)), _i64(alpha.shape[0]), ptr(grad_weights), ptr(grad_last), ptr(g),
                stream_of(alpha))

@@ -72,7 +72,7 @@ def viewdir_embed(viewdirs, viewfreq):
     from ._lib import _flt  # noqa: F401
     N, F = viewdirs.shape[0], viewfreq.shape[0]
     emb = torch.empty((N, 3 + 6 * F), dtype=torch.float32, device=viewdirs.device)
-    with torch.cuda.device_of(viewdirs):
+    with L.device_of(viewdirs):
         L.call('dvgo_viewdir_embed', ptr(viewdirs.contiguous()), ptr(viewfreq), _int(F), _i64(N), ptr(emb),
                stream_of(viewdirs))
     return emb
@@ -108,7 +108,7 @@ class _Shade(torch.autograd.Function):
         H1 = torch.empty((M, width), dtype=torch.float32, device=feat.device) if train else None
         H2 = torch.empty((M, width), dtype=torch.float32, device=feat.device) if train else None
         masks = torch.empty((M, 4), dtype=torch.int64, device=feat.device) if train else None
-        with torch.cuda.device_of(feat):
+        with L.device_of(feat):
             L.call('dvgo_shade_fwd', ptr(feat), _int(C), ptr(emb), _int(E), ptr(ray_id), _i64(M), ptr(W1.contiguous()),
                    ptr(b1.contiguous()), ptr(W2.contiguous()), ptr(b2.contiguous()), ptr(W3.contiguous()),
                    ptr(b3.contiguous()), _int(width), _int(d_in), _int(1 if diffuse else 0), ptr(rgb), ptr(H1), ptr(H2),
@@ -129,7 +129,7 @@ class _Shade(torch.autograd.Function):
         g_feat = torch.empty_like(feat)
         G1 = torch.empty_like(H1)
         gz = torch.empty_like(rgb)
-        with torch.cuda.device_of(feat):
+        with L.device_of(feat):
             L.call('dvgo_shade_bwd', ptr(g_rgb.contiguous()), ptr(rgb), ptr(masks), _i64(M), ptr(W1.contiguous()),
                    ptr(W2.contiguous()), ptr(W3.contiguous()), _int(width), _int(d_in), _int(C), _int(1 if diffuse else 0),
                    ptr(g_feat), ptr(G1), ptr(gz), stream_of(feat))
@@ -139,7 +139,7 @@ class _Shade(torch.autograd.Function):
             psize = width * width + width * 64 + 32 * width + 3 * width
             part = torch.empty((n_parts, psize), dtype=torch.float32, device=feat.device)
             tot = torch.empty(psize, dtype=torch.float32, device=feat.device)
-            with torch.cuda.device_of(feat):
+            with L.device_of(feat):
                 L.call('dvgo_shade_wgrad', ptr(G1), ptr(gz), ptr(masks), ptr(W3.contiguous()), ptr(H1), ptr(H2), ptr(feat), _int(C), ptr(emb),
                        _int(emb.shape[1]), ptr(ray_id), _i64(M), _int(width), _int(1 if diffuse else 0), _int(n_parts),
                        ptr(part), ptr(tot), stream_of(feat))

@@ -82,6 +82,7 @@ def render_loss(render_result, target, n_rays_global, cfg_train):
 
 class _FusedLoss(torch.autograd.Function):
     """render_loss in one pass (csrc/loss.hip): the value and d/d{rgb_marched, alphainv_last, raw_rgb}."""
+    unit_grad = False        # set by TrainStep around its own loss.backward() (saves three scaling launches)
 
     @staticmethod
     def forward(ctx, rgb_marched, alphainv_last, raw_rgb, weights, ray_id, target, n_global, w_main, w_ent, w_per):
@@ -94,7 +95,7 @@ class _FusedLoss(torch.autograd.Function):
         g_last = torch.empty_like(alphainv_last)
         g_raw = torch.empty_like(raw_rgb) if w_per > 0 else None
         loss = torch.empty((), dtype=torch.float32, device=dev)
-        with torch.cuda.device_of(rgb_marched):
+        with L.device_of(rgb_marched):
             L.call('dvgo_loss_fwd_bwd', ptr(rgb_marched), ptr(alphainv_last), ptr(target.contiguous()), _i64(N), ptr(raw_rgb),
                    ptr(weights.contiguous()), ptr(ray_id), _i64(M), _i64(int(n_global)), _flt(w_main), _flt(w_ent),
                    _flt(w_per), ptr(g_marched), ptr(g_last), ptr(g_raw), ptr(loss), stream_of(rgb_marched))
@@ -106,6 +107,8 @@ class _FusedLoss(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, go):
         g_marched, g_last, g_raw = ctx.saved_tensors
+        if _FusedLoss.unit_grad:         # TrainStep calls loss.backward() itself: d loss / d loss = 1, nothing to scale
+            return (g_marched, g_last, g_raw if ctx.has_raw else None, None, None, None, None, None, None, None)
         return (g_marched * go, g_last * go, (g_raw * go) if ctx.has_raw else None, None, None, None, None, None, None,
                 None)
 
@@ -234,7 +237,11 @@ class TrainStep:
         # all-reduce has been STARTED -- its persistent workgroups fill every CU, and RCCL's kernels, arriving
         # second, would sit behind them; arriving first they keep their CUs and the two overlap
         with defer_wgrad(side_stream=self.overlap_wgrad and self.world == 1) as deferred:
-            loss.backward()
+            _FusedLoss.unit_grad = True
+            try:
+                loss.backward()
+            finally:
+                _FusedLoss.unit_grad = False
         works = self.reduce_grids_async()
         deferred.flush()
         self.reduce_small()

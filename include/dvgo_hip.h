@@ -233,12 +233,12 @@ int dvgo_march_composite(const float* weights, const float* rgb /* [M3,3] */,
 
 /* Backward of the composite w.r.t. weights and rgb (either output may be NULL):
  *   grad_weights[i] = sum_c g[r,c]*rgb[i,c] ; grad_rgb[i,c] = g[r,c]*weights[i], r = ray_id[i].
- *   (d/d alphainv_last = bg * sum_c g[r,c] is an N-sized reduction left to the caller;
- *   grad_last_add is reserved and ignored.) */
+ *   grad_last (NULL or [n_rays]) = bg * sum_c g[r,c], the gradient w.r.t. alphainv_last (lib/dvgo.py:559),
+ *   written by the same launch. */
 int dvgo_march_composite_bwd(const float* grad_rgb_marched /* [N,3] */, const float* weights,
                              const float* rgb, const int64_t* ray_id, int64_t M3, int64_t n_rays,
                              float bg, float* grad_weights /* [M3] */, float* grad_rgb /* [M3,3] */,
-                             float* grad_last_add, void* stream);
+                             float* grad_last, void* stream);
 
 /* dvgo_march_feat_bwd: scatter grad_feat [M3,C] into grad_k0 (float atomics, de-duplicated per wavefront in LDS;
  *   element strides sC,sX,sY,sZ of the destination).
