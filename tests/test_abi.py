@@ -29,6 +29,27 @@ def test_library_exports_every_declared_symbol(so_path):
     assert lib.dvgo_abi_version() == _lib.ABI_VERSION
 
 
+def test_argument_validation_returns_error_codes_before_any_launch(so_path):
+    """Every entry point checks sizes and pointers first and returns DVGO_EINVAL (-1) / DVGO_ERANGE (-2) without
+    touching the device -- which is also what makes these calls safe on a host without a GPU."""
+    lib = ctypes.CDLL(so_path)
+    vp, i64, f = ctypes.c_void_p, ctypes.c_int64, ctypes.c_float
+    null = vp(0)
+    assert lib.dvgo_raw2alpha(null, f(0), f(0.5), i64(-1), null, null, null) == -1          # negative size
+    assert lib.dvgo_raw2alpha(null, f(0), f(0.5), i64(0), null, null, null) == 0            # empty input: no-op
+    assert lib.dvgo_raw2alpha(null, f(0), f(0.5), i64(8), null, null, null) == -1           # null pointers
+    assert lib.dvgo_exclusive_scan_i32(null, i64(4), null, null) == -1
+    assert lib.dvgo_grid_grad_split(null, i64(10), ctypes.c_int(16), ctypes.c_int(12), null, null, null) == -1
+    assert lib.dvgo_grid_grad_split(null, i64(0), ctypes.c_int(16), ctypes.c_int(12), null, null, null) == 0
+    one = vp(16)      # any non-null value: rejected on shape before it could be dereferenced
+    assert lib.dvgo_grid_grad_split(one, i64(10), ctypes.c_int(12), ctypes.c_int(12), one, one, null) == -2   # rows of 16 only
+    # colour head: shapes outside the built set are DVGO_ERANGE (the caller then keeps the torch modules)
+    args = [one, ctypes.c_int(12), one, ctypes.c_int(27), one, i64(5), one, one, one, one, one, one]
+    assert lib.dvgo_shade_fwd(*args, ctypes.c_int(96), ctypes.c_int(39), ctypes.c_int(0), one, null, null, null, null) == -2
+    assert lib.dvgo_shade_fwd(*args, ctypes.c_int(128), ctypes.c_int(38), ctypes.c_int(0), one, null, null, null, null) == -1  # d_in != C + E
+    assert lib.dvgo_set_tuning(ctypes.c_int(99), ctypes.c_int(1)) == -1
+
+
 def test_library_has_gfx950_code_object(so_path):
     out = subprocess.run(['/opt/rocm/lib/llvm/bin/llvm-readelf', '-S', so_path], capture_output=True, text=True)
     assert '.hip_fatbin' in out.stdout
