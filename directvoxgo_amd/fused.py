@@ -135,6 +135,7 @@ class _FusedMarch(torch.autograd.Function):
         ctx.save_for_backward(rec2, n2, n_steps, cum if cum is not None else n_steps, off3, start, dirs, last,
                               ray_id, step_id)
         ctx.mark_non_differentiable(alpha, ray_id, step_id, off3)
+        ctx.set_materialize_grads(False)     # no zero-filled [M3] int64 'gradients' for the id outputs (33 MB per step)
         return weights, alpha, last, feat, ray_id, step_id, off3
 
     @staticmethod
