@@ -123,7 +123,8 @@ def test_forward_zero_rays_and_no_grad():
         assert res['rgb_marched'].shape == (0, 3) and res['weights'].numel() == 0 and res['depth'].shape == (0,)
 
 
-def test_fused_equals_unfused_on_larger_scene():
+@pytest.mark.parametrize('width,direct', [(32, False), (128, True)])
+def test_fused_equals_unfused_on_larger_scene(width, direct):
     """A 48^3 scene with 2048 camera rays: fused and op-by-op HIP paths agree (the early-stop and
     threshold decisions are taken on values that differ by float rounding only, so allow a handful
     of samples to flip and compare per-ray results)."""
@@ -137,7 +138,7 @@ def test_fused_equals_unfused_on_larger_scene():
     for fused in (True, 'separate', False):
         fused_mod.COMBINED_GRID_GRAD, fused_mod.COMBINED_MIN_RATIO = fused is True, 1e9    # force it on this small scene
         m = DirectVoxGO(sc['xyz_min'], sc['xyz_max'], num_voxels=48 ** 3, num_voxels_base=48 ** 3, alpha_init=1e-2,
-                        fast_color_thres=1e-4, rgbnet_dim=12, rgbnet_width=32, fused=bool(fused))
+                        fast_color_thres=1e-4, rgbnet_dim=12, rgbnet_width=width, rgbnet_direct=direct, fused=bool(fused))
         torch.manual_seed(1)
         for p in m.rgbnet.parameters():
             torch.nn.init.normal_(p, std=0.2)
