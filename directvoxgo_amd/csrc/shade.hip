@@ -33,7 +33,7 @@ static int g_shade_experiment = 0;   // timing experiments only (tools/): bit 0 
 // (forward 0.956 -> 0.92 ms, data gradients 0.775 -> 0.75 ms against 8 wavefronts)
 #define SHADE_THREADS 768
 #define SHADE_WAVES (SHADE_THREADS / 64)
-#define SHADE_BWD_THREADS 768
+#define SHADE_BWD_THREADS 1024      // data-gradient kernel: 16 wavefronts (128 registers each fit): 0.75 -> 0.72 ms
 #define SHADE_BWD_WAVES (SHADE_BWD_THREADS / 64)
 
 template <int WIDTH, int S1>
