@@ -68,6 +68,45 @@ def test_fused_path_full_size_properties():
     assert torch.isfinite(g[1]).all() and float(g[1].abs().sum()) > 0
 
 
+def test_full_size_gradient_paths_agree():
+    """BASELINE configs[1] sizes (160^3, 8192 x 256 kept samples, 12 features, 128-wide rgbnet_direct head on the MFMA
+    kernels): the combined 64-byte-row scatter and the one-scatter-per-grid path give the same grid gradients (same
+    voxels touched: the masked Adam branches on grad != 0), and a second stream for the weight gradients changes
+    nothing."""
+    from directvoxgo_amd import fused as fused_mod
+    from directvoxgo_amd.dvgo import DirectVoxGO
+    from directvoxgo_amd.scenes import roofline_scene
+    from directvoxgo_amd.shade import defer_wgrad
+    from directvoxgo_amd.train import FINE_TRAIN, fused_render_loss
+    sc = roofline_scene(world=160, n_rays=8192, device='cuda')
+    torch.manual_seed(0)
+    m = DirectVoxGO(sc['xyz_min'], sc['xyz_max'], num_voxels=160 ** 3, num_voxels_base=160 ** 3, alpha_init=1e-2,
+                    fast_color_thres=1e-4, rgbnet_dim=12, rgbnet_width=128, rgbnet_direct=True).cuda()
+    with torch.no_grad():
+        m.density.copy_(sc['density']); m.k0.copy_(sc['k0'])
+    rk = dict(near=sc['near'], far=sc['far'], bg=1, stepsize=0.5)
+    outs = []
+    for combined, side in ((True, True), (False, False)):
+        fused_mod.COMBINED_GRID_GRAD = combined
+        m.zero_grad(set_to_none=True)
+        res = m(sc['rays_o'], sc['rays_d'], sc['viewdirs'], **rk)
+        assert res['weights'].numel() == 8192 * 256
+        loss = fused_render_loss(res, sc['target'], 8192, dict(FINE_TRAIN))
+        with defer_wgrad(side_stream=side) as d:
+            loss.backward()
+        d.flush()
+        torch.cuda.synchronize()
+        outs.append([float(loss)] + [p.grad.clone() for p in (m.density, m.k0, *m.rgbnet.parameters())])
+    fused_mod.COMBINED_GRID_GRAD = True
+    a, b = outs
+    assert abs(a[0] - b[0]) <= 1e-6 * abs(b[0])              # (block partial sums meet in float atomics)
+    for x, y in zip(a[1:3], b[1:3]):                       # grids: atomic summation order differs, nothing else
+        assert torch.equal(x != 0, y != 0)
+        assert float((x - y).abs().max()) <= 2e-5 * float(y.abs().max())
+    for x, y in zip(a[3:], b[3:]):                         # colour head: same kernels; partial sums meet in float atomics
+        assert float((x - y).abs().max()) <= 1e-5 * float(y.abs().max())
+
+
 def test_two_stage_flow_coarse_to_fine(tmp_path):
     """run.py:440-492 on in-memory rays: coarse stage (colour grid, per-voxel ops) -> checkpoint -> bbox from the
     coarse geometry -> fine stage seeded by mask_cache_path, trained on the rays that hit the coarse geometry."""
