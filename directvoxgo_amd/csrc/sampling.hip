@@ -101,6 +101,106 @@ scan_kernel(const TIn* __restrict__ in, int64_t n, int64_t* __restrict__ out) {
   if (EXCLUSIVE && tid == 0) out[n] = carry_s;
 }
 
+// Long inputs (full-image ray chunks: 65536 rays and more) in three short launches instead of one workgroup walking
+// the array (65 us at 65536): block totals -> scan of the totals -> per-block scan with its carry.  The totals live in
+// the first output slot of each block's own range (read back as the carry before that range is written), so no
+// scratch buffer is needed.
+#define DVGO_SCAN_TILE 8192      // items per workgroup: 1024 threads x 8
+template <typename TIn>
+__global__ void __launch_bounds__(1024)
+scan_block_totals_kernel(const TIn* __restrict__ in, int64_t n, int64_t* __restrict__ out) {
+  __shared__ int64_t wave_sums[16];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int64_t i0 = (int64_t)blockIdx.x * DVGO_SCAN_TILE + (int64_t)tid * 8;
+  int64_t t = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) t += (i0 + k < n) ? (int64_t)in[i0 + k] : 0;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d);
+  if (lane == 0) wave_sums[wid] = t;
+  __syncthreads();
+  if (tid == 0) {
+    int64_t tot = 0;
+    for (int w = 0; w < 16; ++w) tot += wave_sums[w];
+    out[(int64_t)blockIdx.x * DVGO_SCAN_TILE] = tot;
+  }
+}
+
+// exclusive scan, in place, of the nb strided totals out[b * TILE]; the grand total goes to *total when given
+__global__ void __launch_bounds__(1024)
+scan_totals_kernel(int64_t* __restrict__ out, int64_t nb, int64_t* __restrict__ total) {
+  __shared__ int64_t wave_sums[16];
+  __shared__ int64_t carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < nb; base += 1024) {
+    const int64_t b = base + tid;
+    const int64_t v = (b < nb) ? out[b * DVGO_SCAN_TILE] : 0;
+    int64_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int64_t o = __shfl_up(inc, d);
+      if (lane >= d) inc += o;
+    }
+    if (lane == 63) wave_sums[wid] = inc;
+    __syncthreads();
+    int64_t wave_off = 0;
+    for (int w = 0; w < wid; ++w) wave_off += wave_sums[w];
+    const int64_t excl = carry_s + wave_off + inc - v;
+    if (b < nb) out[b * DVGO_SCAN_TILE] = excl;
+    __syncthreads();
+    if (tid == 1023) carry_s = excl + v;
+    __syncthreads();
+  }
+  if (total != nullptr && tid == 0) *total = carry_s;
+}
+
+template <typename TIn, bool EXCLUSIVE>
+__global__ void __launch_bounds__(1024)
+scan_blocks_kernel(const TIn* __restrict__ in, int64_t n, int64_t* __restrict__ out) {
+  __shared__ int64_t wave_sums[16];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int64_t base = (int64_t)blockIdx.x * DVGO_SCAN_TILE;
+  const int64_t carry = out[base];                  // this block's exclusive prefix, left there by scan_totals_kernel
+  const int64_t i0 = base + (int64_t)tid * 8;
+  int64_t v[8];
+  int64_t tsum = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    v[k] = (i0 + k < n) ? (int64_t)in[i0 + k] : 0;
+    tsum += v[k];
+  }
+  int64_t inc = tsum;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int64_t o = __shfl_up(inc, d);
+    if (lane >= d) inc += o;
+  }
+  if (lane == 63) wave_sums[wid] = inc;
+  __syncthreads();                                  // also: every thread has read `carry` before anyone writes out[base]
+  int64_t wave_off = 0;
+  for (int w = 0; w < wid; ++w) wave_off += wave_sums[w];
+  int64_t run = carry + wave_off + inc - tsum;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    if (EXCLUSIVE) { if (i0 + k < n) out[i0 + k] = run; run += v[k]; }
+    else           { run += v[k]; if (i0 + k < n) out[i0 + k] = run; }
+  }
+}
+
+template <typename TIn, bool EXCLUSIVE>
+static void launch_scan(const TIn* in, int64_t n, int64_t* out, hipStream_t s) {
+  if (n <= 2 * DVGO_SCAN_TILE || (const void*)in == (const void*)out) {     // short (or in place): one workgroup
+    scan_kernel<TIn, EXCLUSIVE><<<1, 1024, 0, s>>>(in, n, out);
+    return;
+  }
+  const int64_t nb = (n + DVGO_SCAN_TILE - 1) / DVGO_SCAN_TILE;
+  scan_block_totals_kernel<TIn><<<(int)nb, 1024, 0, s>>>(in, n, out);
+  scan_totals_kernel<<<1, 1024, 0, s>>>(out, nb, EXCLUSIVE ? out + n : nullptr);
+  scan_blocks_kernel<TIn, EXCLUSIVE><<<(int)nb, 1024, 0, s>>>(in, n, out);
+}
+
 // ----------------------------------------------------------------------------------
 // K4 + K5 + K6 as one flat pass over the M0 samples: each sample finds its ray by
 // binary search in the inclusive cumsum (lanes of a wave mostly share a ray, so the
@@ -210,7 +310,7 @@ int dvgo_sample_pts_prepare(const float* rays_o, const float* rays_d, const floa
       n_steps, rays_start, rays_dir);
   DVGO_LAUNCH_CHECK();
   if (n_steps_cumsum) {   // NULL: caller uses fixed-stride scratch and does not need M0
-    scan_kernel<int64_t, false><<<1, 1024, 0, s>>>(n_steps, n_rays, n_steps_cumsum);
+    launch_scan<int64_t, false>(n_steps, n_rays, n_steps_cumsum, s);
     DVGO_LAUNCH_CHECK();
   }
   return 0;
@@ -252,7 +352,7 @@ int dvgo_exclusive_scan_i32(const int32_t* counts, int64_t n, int64_t* offsets, 
   if (!offsets) return DVGO_EINVAL;
   if (n == 0) { DVGO_HIP_TRY(hipMemsetAsync(offsets, 0, sizeof(int64_t), (hipStream_t)stream)); return 0; }
   if (!counts) return DVGO_EINVAL;
-  scan_kernel<int32_t, true><<<1, 1024, 0, (hipStream_t)stream>>>(counts, n, offsets);
+  launch_scan<int32_t, true>(counts, n, offsets, (hipStream_t)stream);
   DVGO_LAUNCH_CHECK();
   return 0;
 }

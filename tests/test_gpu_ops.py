@@ -297,6 +297,29 @@ def test_total_variation(ops, oracle, dense, shape):
         np.testing.assert_array_equal(gt.cpu().numpy(), exp)
 
 
+@pytest.mark.parametrize('n', [1, 8192, 16384, 16385, 100000, 1000003])
+def test_scans_short_and_long(n):
+    """One-workgroup scan up to 16384 items, three-launch block scan above (full-image ray chunks)."""
+    from directvoxgo_amd import _lib as L
+    from directvoxgo_amd._lib import _flt, _i64, ptr, stream_of
+    g = torch.Generator(device='cuda').manual_seed(n)
+    counts = torch.randint(0, 300, (n,), device='cuda', dtype=torch.int32, generator=g)
+    off = torch.empty(n + 1, dtype=torch.int64, device='cuda')
+    L.call('dvgo_exclusive_scan_i32', ptr(counts), _i64(n), ptr(off), stream_of(counts))
+    ref = torch.cat([torch.zeros(1, dtype=torch.int64, device='cuda'), counts.long().cumsum(0)])
+    assert torch.equal(off, ref)
+    # inclusive int64 scan: the n_steps cumsum of dvgo_sample_pts_prepare
+    ro = torch.rand(n, 3, device='cuda', generator=g) * 0.2 - 3.0
+    rd = torch.nn.functional.normalize(torch.rand(n, 3, device='cuda', generator=g) + 0.2, dim=-1)
+    mn, mx = torch.tensor([-1.0, -1.0, -1.0], device='cuda'), torch.tensor([1.0, 1.0, 1.0], device='cuda')
+    t_min, t_max = torch.empty(n, device='cuda'), torch.empty(n, device='cuda')
+    n_steps, cum = torch.empty(n, dtype=torch.int64, device='cuda'), torch.empty(n, dtype=torch.int64, device='cuda')
+    start, dirs = torch.empty(n, 3, device='cuda'), torch.empty(n, 3, device='cuda')
+    L.call('dvgo_sample_pts_prepare', ptr(ro), ptr(rd), ptr(mn), ptr(mx), _flt(0.2), _flt(8.0), _flt(0.01), _i64(n), ptr(t_min),
+           ptr(t_max), ptr(n_steps), ptr(cum), ptr(start), ptr(dirs), stream_of(ro))
+    assert torch.equal(cum, n_steps.cumsum(0)) and int(n_steps.max()) > 1
+
+
 # ------------------------------------------------------------------ N3 fused colour head
 @pytest.mark.parametrize('M,diffuse,width,C,E', [
     (1, True, 128, 12, 27), (31, True, 128, 12, 27), (1000, False, 128, 12, 27), (70001, True, 128, 12, 27),
