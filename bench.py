@@ -267,9 +267,10 @@ def main():
         M0, M_d, M_k = count_samples(m, pool[0], rk)
         step = TrainStep(m, dict(FINE_TRAIN), rk)
         dt, prof = timed_region(step, pool, steps, warmup, world, profile)
-        return sc, m, rk, dt, prof, (M0, M_d, M_k)
+        end_counts = count_samples(m, pool[0], rk)          # the optimizer moves the scene: how far did the workload drift?
+        return sc, m, rk, dt, prof, (M0, M_d, M_k), end_counts
 
-    sc, m, rk, dt, prof, (M0, M_d, M_k) = run(args.workload, args.steps, args.warmup, True)
+    sc, m, rk, dt, prof, (M0, M_d, M_k), end_counts = run(args.workload, args.steps, args.warmup, True)
     n_total = args.rays * world
     value = n_total * args.steps / dt
 
@@ -309,13 +310,14 @@ def main():
         'config': {'workload': f'cfg2 {args.workload}: {args.world}^3 fine grid, k0_dim 12 + rgbnet 3x128, '
                                f'{args.rays} rays/GPU x {M0 // args.rays} samples/ray '
                                f'(M_d={M_d}, M_k={M_k} per GPU per step), full train step',
-                   'rays_per_gpu': args.rays, 'grid': args.world, 'parallelism': f'ray-dp{world}'},
+                   'rays_per_gpu': args.rays, 'grid': args.world, 'parallelism': f'ray-dp{world}',
+                   'samples_after_run': {'M_d': end_counts[1], 'M_k': end_counts[2]}},
         'roofline': roofline, 'north_star_kernels': ns, 'kernels': kernels,
         'kernel_timing': 'HIP events around each launch, second pass of the same K steps with all kernels on one stream',
     }
 
     if rank == 0 and world == 1 and not args.no_secondary and args.workload == 'roofline':
-        sc2, m2, rk2, dt2, prof2, (M0b, M_db, M_kb) = run('lego', max(args.steps, 20), args.warmup, False)
+        sc2, m2, rk2, dt2, prof2, (M0b, M_db, M_kb), _ = run('lego', max(args.steps, 20), args.warmup, False)
         out['lego_like'] = {'value': args.rays * max(args.steps, 20) / dt2, 'unit': 'rays/s',
                             'ms_per_step': dt2 / max(args.steps, 20) * 1e3, 'occupancy': sc2['occupancy'],
                             'samples_per_ray': {'M0': M0b / args.rays, 'M_d': M_db / args.rays, 'M_k': M_kb / args.rays}}
