@@ -5,6 +5,7 @@ On the GPU box (one gpurun call; counters in their own passes, as MI355X_MICROAR
     rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_kt    -- python $R/bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-secondary
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_fetch -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-secondary
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_write -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-secondary
+    rocprofv3 --pmc TCC_EA0_ATOMIC_sum --output-format csv -d $R/gpurun_out/prof_atom -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-secondary   (optional)
 Here:
     python tools/make_profiles.py gpurun_out profiles/r1 "note for the summary header"
 """
@@ -71,10 +72,22 @@ def pmc(src, dst, workload, grid, rays):
             acc.setdefault(e, {})[counter + '_KB'] = d[counter] / max(len(launches[e]), 1)
     for e, d in acc.items():
         d['hbm_bytes'] = (2 * d.get('FETCH_SIZE_KB', 0.0) + d.get('WRITE_SIZE_KB', 0.0)) * 1024
+    atom = {}
+    hits = glob.glob(os.path.join(src, 'prof_atom', '**', '*counter_collection.csv'), recursive=True)
+    if hits:        # optional fourth pass: rocprofv3 --pmc TCC_EA0_ATOMIC_sum (memory-side atomic requests per launch)
+        per, n = defaultdict(float), defaultdict(set)
+        for r in csv.DictReader(open(sorted(hits)[-1])):
+            e = entry_of(r['Kernel_Name'])
+            if r['Counter_Name'] == 'TCC_EA0_ATOMIC_sum' and e is not None:
+                per[e] += float(r['Counter_Value'])
+                n[e].add(r['Dispatch_Id'])
+        atom = {e: per[e] / max(len(n[e]), 1) for e in per if per[e] > 0}
     out = {'_about': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `python bench.py --steps 3 --warmup 2 '
                      '--no-cpu-baseline --no-secondary`; per-launch averages. hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024: '
                      'gfx950 FETCH_SIZE reports half of 16-B-per-lane reads (MI355X_MICROARCH.md HBM section).',
            'workload': workload, 'grid': grid, 'rays': rays, 'kernels': acc}
+    if atom:
+        out['atomic_requests'] = atom
     json.dump(out, open(os.path.join(dst, 'pmc_traffic.json'), 'w'), indent=1)
 
 
