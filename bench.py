@@ -38,7 +38,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/
 
 HOT_KERNELS = ['dvgo_sample_pts_prepare', 'dvgo_march_density', 'dvgo_exclusive_scan_i32', 'dvgo_march_gather',
                'dvgo_march_composite', 'dvgo_march_composite_bwd', 'dvgo_march_feat_bwd', 'dvgo_march_density_bwd',
-               'dvgo_grid_grad_split', 'dvgo_adam_upd', 'dvgo_shade_fwd', 'dvgo_shade_bwd', 'dvgo_shade_wgrad']
+               'dvgo_grid_grad_split', 'dvgo_adam_rows', 'dvgo_adam_upd', 'dvgo_shade_fwd', 'dvgo_shade_bwd', 'dvgo_shade_wgrad']
 
 
 def algorithmic_bytes(name, N, M_d, M2, M_k, C, n_grid):
@@ -55,6 +55,7 @@ def algorithmic_bytes(name, N, M_d, M2, M_k, C, n_grid):
                                                                             # density gradient rides as channel C
         'dvgo_march_density_bwd': M2 * 16 + M_k * 4 + (M2 - M_k) * 8 * 4,   # rec2 read, kept list, dropped-sample atomics
         'dvgo_grid_grad_split': None,                                       # per call: 64 B read + 52 B written per voxel
+        'dvgo_adam_rows': None,                                             # per call: 64 B row + 6 x 52 B of p / m / v per voxel
         'dvgo_adam_upd': None,                                              # per call: 28 B / element (dense)
         # colour head (row N3): MFMA-bound, bytes listed for completeness (features / activations in and out)
         'dvgo_shade_fwd': M_k * (C * 4 + 8 + 12 + 2 * 512),
@@ -286,6 +287,8 @@ def main():
             ab = 28 * n_grid / max(cnt / args.steps, 1)          # average per call over the param tensors
         if name == 'dvgo_grid_grad_split':
             ab = (64 + 52) * m.density.numel()
+        if name == 'dvgo_adam_rows':
+            ab = (64 + 6 * 52) * m.density.numel()
         kernels[name] = {'launches': cnt, 'avg_ms': per_ms, 'alg_bytes': ab,
                          'GBps': ab / per_ms / 1e6, 'frac': ab / per_ms / 1e6 / HBM_PEAK_GBS}
     march = {k: v for k, v in kernels.items() if k in ('dvgo_march_gather', 'dvgo_march_feat_bwd', 'dvgo_march_density',

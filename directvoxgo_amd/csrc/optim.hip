@@ -48,6 +48,36 @@ adam_kernel(float* __restrict__ param, const float* __restrict__ grad, float* __
   }
 }
 
+// Adam straight from the combined gradient rows of the fused march backward (march.hip: [n_vox][16] floats = 12 feature
+// channels, the density gradient, 3 pad): updates the channels-last feature grid and the density grid in one pass and
+// saves the split into two dense gradients plus their re-read (0.07 ms per step at 160^3).  Element-wise maths and the
+// masked rule are those of adam_kernel<0/1>; 4 threads per row, one float4 each.
+template <int MODE_K, int MODE_D>
+__global__ void __launch_bounds__(DVGO_BLOCK)
+adam_rows_kernel(const float* __restrict__ G, int64_t n_vox, float* __restrict__ pk, float* __restrict__ mk,
+                 float* __restrict__ vk, float ss_k, float* __restrict__ pd, float* __restrict__ md,
+                 float* __restrict__ vd, float ss_d, float beta1, float beta2, float eps) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t row = t >> 2;
+  const int q = (int)(t & 3);
+  if (row >= n_vox) return;
+  const float4 g = reinterpret_cast<const float4*>(G)[row * 4 + q];
+  if (q < 3) {
+    if (MODE_K == 1 && g.x == 0.f && g.y == 0.f && g.z == 0.f && g.w == 0.f) return;
+    const int64_t i = row * 3 + q;
+    float4 p = reinterpret_cast<float4*>(pk)[i], m = reinterpret_cast<float4*>(mk)[i], v = reinterpret_cast<float4*>(vk)[i];
+    adam_one<MODE_K>(p.x, g.x, m.x, v.x, 0.f, ss_k, beta1, beta2, eps);
+    adam_one<MODE_K>(p.y, g.y, m.y, v.y, 0.f, ss_k, beta1, beta2, eps);
+    adam_one<MODE_K>(p.z, g.z, m.z, v.z, 0.f, ss_k, beta1, beta2, eps);
+    adam_one<MODE_K>(p.w, g.w, m.w, v.w, 0.f, ss_k, beta1, beta2, eps);
+    reinterpret_cast<float4*>(pk)[i] = p;
+    reinterpret_cast<float4*>(mk)[i] = m;
+    reinterpret_cast<float4*>(vk)[i] = v;
+  } else {
+    adam_one<MODE_D>(pd[row], g.x, md[row], vd[row], 0.f, ss_d, beta1, beta2, eps);
+  }
+}
+
 __device__ __forceinline__ float clamp1(float v) { return fminf(fmaxf(v, -1.f), 1.f); }
 
 // One thread per grid element.  `cl` selects the thread -> element order so that consecutive
@@ -132,6 +162,27 @@ int dvgo_adam_upd(float* param, const float* grad, float* exp_avg, float* exp_av
     adam_kernel<1><<<blocks, DVGO_BLOCK, 0, s>>>(param, grad, exp_avg, exp_avg_sq, perlr, n, step_size, beta1, beta2, eps, vec);
   else
     adam_kernel<2><<<blocks, DVGO_BLOCK, 0, s>>>(param, grad, exp_avg, exp_avg_sq, perlr, n, step_size, beta1, beta2, eps, vec);
+  DVGO_LAUNCH_CHECK();
+  return 0;
+}
+
+int dvgo_adam_rows(const float* G, int64_t n_vox, int row_stride, int C, float* p_k0, float* m_k0, float* v_k0,
+                   float step_size_k0, int mode_k0, float* p_density, float* m_density, float* v_density,
+                   float step_size_density, int mode_density, float beta1, float beta2, float eps, void* stream) {
+  if (n_vox < 0 || mode_k0 < 0 || mode_k0 > 1 || mode_density < 0 || mode_density > 1) return DVGO_EINVAL;
+  if (n_vox == 0) return 0;
+  if (!G || !p_k0 || !m_k0 || !v_k0 || !p_density || !m_density || !v_density) return DVGO_EINVAL;
+  if (row_stride != 16 || C != 12) return DVGO_ERANGE;
+  if ((((uintptr_t)G | (uintptr_t)p_k0 | (uintptr_t)m_k0 | (uintptr_t)v_k0) & 15) != 0) return DVGO_EINVAL;
+  if (!dvgo_fits(n_vox * 4)) return DVGO_ERANGE;
+  const int blocks = dvgo_blocks(n_vox * 4, DVGO_BLOCK);
+  hipStream_t s = (hipStream_t)stream;
+#define DVGO_ADAM_ROWS(MK, MD)                                                                                          \
+  adam_rows_kernel<MK, MD><<<blocks, DVGO_BLOCK, 0, s>>>(G, n_vox, p_k0, m_k0, v_k0, step_size_k0, p_density, m_density, \
+                                                         v_density, step_size_density, beta1, beta2, eps)
+  if (mode_k0 == 1) { if (mode_density == 1) DVGO_ADAM_ROWS(1, 1); else DVGO_ADAM_ROWS(1, 0); }
+  else              { if (mode_density == 1) DVGO_ADAM_ROWS(0, 1); else DVGO_ADAM_ROWS(0, 0); }
+#undef DVGO_ADAM_ROWS
   DVGO_LAUNCH_CHECK();
   return 0;
 }

@@ -66,6 +66,35 @@ COMBINED_GRID_GRAD = True
 COMBINED_MIN_RATIO = 6          # use it when kept samples * ratio >= voxels (tests set 1e9 to force it)
 
 
+class grid_rows_capture:
+    """Context manager for a training step that owns the optimizer: inside it, a backward that scattered into combined
+    gradient rows hands them over (`.G`: [n_vox, 16] = 12 feature channels, the density gradient, pad) INSTEAD of
+    splitting them into `k0.grad` / `density.grad` -- those two stay `None` -- so that the optimizer can update both
+    grids straight from the rows (`MaskedAdam.step_grid_rows`).  Only for the (density, k0) parameters given."""
+    _active = None
+
+    def __init__(self, density, k0):
+        self.density, self.k0, self.G = density, k0, None
+
+    def __enter__(self):
+        self.G = None
+        grid_rows_capture._active = self
+        return self
+
+    def __exit__(self, *exc):
+        grid_rows_capture._active = None
+        return False
+
+
+def split_grid_rows(G, density, k0):
+    """Combined gradient rows -> (density.grad, k0.grad) in the parameters' own layouts."""
+    gk = torch.empty_like(k0, memory_format=torch.preserve_format)
+    gd = torch.empty_like(density)
+    with L.device_of(G):
+        L.call('dvgo_grid_grad_split', ptr(G), _i64(density.numel()), _int(16), _int(k0.shape[1]), ptr(gk), ptr(gd), stream_of(G))
+    return gd, gk
+
+
 class _FusedMarch(torch.autograd.Function):
     @staticmethod
     def forward(ctx, density, k0, rays_o, rays_d, cfg):
@@ -175,6 +204,10 @@ class _FusedMarch(torch.autograd.Function):
                 L.call('dvgo_march_feat_bwd', ptr(g_feat.contiguous()), ptr(kept), ptr(ray_id), ptr(step_id), _i64(M3),
                        ptr(start), ptr(dirs), _flt(cfg.stepdist), cfg.xyz_min_h, cfg.xyz_max_h, _int(C), _int(X),
                        _int(Y), _int(Z), _i64(1), _i64(Y * Z * 16), _i64(Z * 16), _i64(16), ptr(G), st)
+                cap = grid_rows_capture._active
+                if cap is not None and cap.G is None and cap.density is ctx.density_meta and cap.k0 is ctx.k0_meta:
+                    cap.G = G                  # the optimizer consumes the rows; no dense gradients are produced
+                    return None, None, None, None, None
                 grad_k0 = torch.empty_like(ctx.k0_meta, memory_format=torch.preserve_format)
                 grad_density = torch.empty_like(ctx.density_meta)
                 assert grad_k0.stride() == ctx.k0_meta.stride() and grad_density.is_contiguous()

@@ -90,6 +90,40 @@ class MaskedAdam(torch.optim.Optimizer):
             return t
         return torch.empty_like(p, memory_format=torch.preserve_format).copy_(t)
 
+    def _group_of(self, p):
+        for group in self.param_groups:
+            if any(q is p for q in group['params']):
+                return group
+        return None
+
+    def can_step_grid_rows(self, density, k0):
+        """True when `step_grid_rows` reproduces what `step` would do for these two parameters."""
+        gd, gk = self._group_of(density), self._group_of(k0)
+        if gd is None or gk is None or gd['betas'] != gk['betas'] or gd['eps'] != gk['eps']:
+            return False
+        if self.per_lr is not None and self.per_lr.shape in (density.shape, k0.shape):
+            return False                                  # per-voxel learning rates go through the dense kernels
+        return (k0.dim() == 5 and k0.shape[1] == 12 and k0.is_contiguous(memory_format=torch.channels_last_3d)
+                and density.is_contiguous() and density.shape[2:] == k0.shape[2:])
+
+    @torch.no_grad()
+    def step_grid_rows(self, density, k0, G):
+        """The update of `step()` for the density and feature grids, read from the combined gradient rows G
+        ([n_vox, 16], fused.grid_rows_capture) in one pass (csrc/optim.hip adam_rows_kernel)."""
+        gd, gk = self._group_of(density), self._group_of(k0)
+        sd, sk = self._state_of(density), self._state_of(k0)
+        sd['step'] += 1
+        sk['step'] += 1
+        b1, b2 = gk['betas']
+        n_vox = density.numel()
+        assert G.shape == (n_vox, 16) and G.is_contiguous()
+        with L.device_of(k0):
+            L.call('dvgo_adam_rows', ptr(G), _i64(n_vox), _int(16), _int(12), ptr(k0), ptr(sk['exp_avg']), ptr(sk['exp_avg_sq']),
+                   _flt(adam_step_size(gk['lr'], b1, b2, sk['step'])), _int(1 if gk.get('skip_zero_grad', False) else 0),
+                   ptr(density), ptr(sd['exp_avg']), ptr(sd['exp_avg_sq']),
+                   _flt(adam_step_size(gd['lr'], b1, b2, sd['step'])), _int(1 if gd.get('skip_zero_grad', False) else 0),
+                   _flt(b1), _flt(b2), _flt(gk['eps']), stream_of(k0))
+
     @torch.no_grad()
     def step(self):
         for group in self.param_groups:

@@ -14,11 +14,14 @@ the small MLP gradients travel in one flat bucket.  TV and the masked Adam run a
 reduction because both branch on ``grad != 0`` (total_variation_kernel.cu:21,
 adam_upd_kernel.cu:35) and must see the reduced gradient.
 """
+import contextlib
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
 
 from .masked_adam import MaskedAdam
+from .fused import grid_rows_capture, split_grid_rows
 from .shade import defer_wgrad
 
 def flat_view(t):
@@ -125,8 +128,11 @@ class TrainStep:
     """One optimisation step on one batch of rays; ``world_size > 1`` shards the batch by rank."""
 
     def __init__(self, model, cfg_train, render_kwargs, optimizer=None, process_group=None, fused_loss=True,
-                 overlap_wgrad=True, touched_reduce=True):
+                 overlap_wgrad=True, touched_reduce=True, rows_adam=True):
         self.model = model
+        # one GPU, no TV this step: Adam reads the combined gradient rows of the fused backward directly
+        # (fused.grid_rows_capture / MaskedAdam.step_grid_rows); density.grad / k0.grad then stay None
+        self.rows_adam = rows_adam
         # data parallel, sparse scenes: all-reduce only the voxels some rank touched (see _reduce_touched)
         self.touched_reduce = touched_reduce
         self._touched_frac = None            # fraction of voxels in the last union; None: not probed yet
@@ -236,12 +242,27 @@ class TrainStep:
         # kernel runs on a second stream beside the scatters.  Data parallel: it is postponed until the grid
         # all-reduce has been STARTED -- its persistent workgroups fill every CU, and RCCL's kernels, arriving
         # second, would sit behind them; arriving first they keep their CUs and the two overlap
-        with defer_wgrad(side_stream=self.overlap_wgrad and self.world == 1) as deferred:
+        tv_now = (cfg['tv_after'] < global_step < cfg['tv_before'] and global_step % cfg['tv_every'] == 0 and
+                  (cfg['weight_tv_density'] > 0 or cfg['weight_tv_k0'] > 0))
+        density, k0 = getattr(model, 'density', None), getattr(model, 'k0', None)
+        use_rows = (self.rows_adam and self.world == 1 and not tv_now and isinstance(self.optimizer, MaskedAdam)
+                    and isinstance(density, nn.Parameter) and isinstance(k0, nn.Parameter) and density.is_cuda
+                    and self.optimizer.can_step_grid_rows(density, k0))
+        rows = grid_rows_capture(density, k0) if use_rows else contextlib.nullcontext()
+        with defer_wgrad(side_stream=self.overlap_wgrad and self.world == 1) as deferred, rows as cap:
             _FusedLoss.unit_grad = True
             try:
                 loss.backward()
             finally:
                 _FusedLoss.unit_grad = False
+        if use_rows and cap.G is not None:
+            if density.grad is None and k0.grad is None:
+                self.optimizer.step_grid_rows(density, k0, cap.G)  # (.grad of the two grids is None: step() below skips them)
+            else:                                                 # more than one march in the graph: fold the rows back
+                gd, gk = split_grid_rows(cap.G, density, k0)
+                density.grad = gd if density.grad is None else density.grad + gd
+                k0.grad = gk if k0.grad is None else k0.grad + gk
+            cap.G = None
         works = self.reduce_grids_async()
         deferred.flush()
         self.reduce_small()

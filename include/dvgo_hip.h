@@ -323,6 +323,15 @@ int dvgo_adam_upd(float* param, const float* grad, float* exp_avg, float* exp_av
                   const float* perlr /* mode 2 only */, int64_t n, float step_size,
                   float beta1, float beta2, float eps, int mode, void* stream);
 
+/* Adam / masked Adam (mode 0 / 1, as dvgo_adam_upd) for the feature grid (channels-last rows [n_vox][C]) and the
+ * density grid [n_vox] straight from the combined gradient rows G [n_vox][row_stride] of dvgo_march_feat_bwd /
+ * dvgo_march_density_bwd -- instead of dvgo_grid_grad_split followed by two dvgo_adam_upd.  Built for row_stride 16,
+ * C 12.  step_size_* as for dvgo_adam_upd (computed by the caller in float, adam_upd_kernel.cu:72). */
+int dvgo_adam_rows(const float* G, int64_t n_vox, int row_stride, int C,
+                   float* p_k0, float* m_k0, float* v_k0, float step_size_k0, int mode_k0,
+                   float* p_density, float* m_density, float* v_density, float step_size_density, int mode_density,
+                   float beta1, float beta2, float eps, void* stream);
+
 int dvgo_total_variation_add_grad(const float* param, float* grad, float wx, float wy, float wz,
                                   int64_t C, int64_t sz_i, int64_t sz_j, int64_t sz_k,
                                   int64_t sC, int64_t sI, int64_t sJ, int64_t sK,

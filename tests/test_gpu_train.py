@@ -238,3 +238,38 @@ def test_two_ranks_on_one_gpu_equal_one_process(mode):
     for k, v in ref_params.items():
         a, b = torch.from_numpy(params[k]), v.cpu()
         assert float((a - b).abs().max()) <= 2e-4 * max(float(b.abs().max()), 1e-3), k
+
+
+def test_adam_from_gradient_rows_equals_dense_path():
+    """TrainStep(rows_adam=True) -- MaskedAdam reading the combined gradient rows of the fused backward -- against the
+    split-into-dense-gradients path: same parameters and optimizer state after three steps (up to float-atomic order),
+    same set of voxels touched (the masked rule), and the two grids' .grad stay None."""
+    from directvoxgo_amd import fused as fused_mod
+    from directvoxgo_amd.dvgo import DirectVoxGO
+    from directvoxgo_amd.scenes import synthetic_scene
+    from directvoxgo_amd.train import FINE_TRAIN, TrainStep
+    sc = synthetic_scene(world=48, n_rays=4096, seed=12, device='cuda')
+    outs = []
+    saved = fused_mod.COMBINED_MIN_RATIO
+    fused_mod.COMBINED_MIN_RATIO = 1e9           # the combined-rows backward on this small scene
+    try:
+        for rows in (True, False):
+            torch.manual_seed(4)
+            m = DirectVoxGO(sc['xyz_min'], sc['xyz_max'], num_voxels=48 ** 3, num_voxels_base=48 ** 3, alpha_init=1e-2,
+                            fast_color_thres=1e-4, rgbnet_dim=12, rgbnet_width=128, rgbnet_direct=True).cuda()
+            with torch.no_grad():
+                m.density.copy_(sc['density']); m.k0.copy_(sc['k0']); m.mask_cache.mask.copy_(sc['mask'])
+            step = TrainStep(m, dict(FINE_TRAIN), dict(near=sc['near'], far=sc['far'], bg=1, stepsize=0.5), rows_adam=rows)
+            for s in range(3):
+                step(sc['rays_o'], sc['rays_d'], sc['viewdirs'], sc['target'], global_step=s)
+            assert (m.k0.grad is None and m.density.grad is None) == rows
+            st = step.optimizer.state
+            outs.append([m.density.detach().clone(), m.k0.detach().clone(), st[m.k0]['exp_avg'].clone(),
+                         st[m.k0]['exp_avg_sq'].clone(), st[m.density]['exp_avg'].clone(), st[m.k0]['step'], st[m.density]['step']])
+    finally:
+        fused_mod.COMBINED_MIN_RATIO = saved
+    a, b = outs
+    assert a[5] == b[5] == 3 and a[6] == b[6] == 3
+    assert torch.equal(a[2] != 0, b[2] != 0)                           # same voxels ever touched
+    for x, y in zip(a[:5], b[:5]):
+        assert float((x - y).abs().max()) <= 1e-4 * max(float(y.abs().max()), 1e-6)

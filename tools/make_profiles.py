@@ -21,7 +21,8 @@ ENTRY = [   # kernel-name fragment -> C-ABI entry point (first match wins)
     ('march_gather_kernel', 'dvgo_march_gather'), ('march_composite_bwd_kernel', 'dvgo_march_composite_bwd'),
     ('march_composite_kernel', 'dvgo_march_composite'), ('march_feat_bwd', 'dvgo_march_feat_bwd'),
     ('grid_grad_split_kernel', 'dvgo_grid_grad_split'), ('shade_fwd_kernel', 'dvgo_shade_fwd'),
-    ('shade_bwd_kernel', 'dvgo_shade_bwd'), ('shade_wgrad_kernel', 'dvgo_shade_wgrad'), ('adam_kernel', 'dvgo_adam_upd'),
+    ('shade_bwd_kernel', 'dvgo_shade_bwd'), ('shade_wgrad_kernel', 'dvgo_shade_wgrad'), ('adam_rows_kernel', 'dvgo_adam_rows'),
+    ('adam_kernel', 'dvgo_adam_upd'),
     ('ray_setup_kernel', 'dvgo_sample_pts_prepare'), ('scan_kernel<int', 'dvgo_exclusive_scan_i32'),
 ]
 
