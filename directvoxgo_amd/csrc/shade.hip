@@ -385,7 +385,7 @@ typedef const __attribute__((address_space(1))) void* dvgo_gptr_t;
 typedef __attribute__((address_space(3))) void* dvgo_lptr_t;
 
 template <int WIDTH>
-__global__ void __launch_bounds__(2 * WIDTH)           // one wavefront per 32-wide out-feature tile
+__global__ void __launch_bounds__(2 * WIDTH) __attribute__((amdgpu_num_vgpr(104)))   // one wavefront per 32-wide out-feature tile; 208 registers
 shade_wgrad_kernel(const float* __restrict__ G1, const float* __restrict__ gz, const unsigned int* __restrict__ masks,
                    const float* __restrict__ W3, const float* __restrict__ H1, const float* __restrict__ H2, const float* __restrict__ feat, int C,
                    int c_view0, int n_view, const float* __restrict__ emb, int E, const int64_t* __restrict__ ray_id,
