@@ -235,6 +235,9 @@ def main():
     ap.add_argument('--world', type=int, default=160, help='grid resolution per axis')
     ap.add_argument('--rays', type=int, default=8192, help='rays per GPU per step')
     ap.add_argument('--workload', default='roofline', choices=['roofline', 'lego'])
+    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
+                    help="weak: --rays per GPU (default, the driver's contract); strong: --rays in total, split over the GPUs "
+                         "(BASELINE configs[2]: one 8192-ray batch sharded over 8 GPUs)")
     ap.add_argument('--no-secondary', action='store_true', help='skip the lego-like secondary measurement')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-rays', type=int, default=4096)
@@ -243,6 +246,9 @@ def main():
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
+    if args.scaling == 'strong':
+        assert args.rays % world == 0
+        args.rays //= world              # from here on: rays per GPU
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     n_dev = torch.cuda.device_count()
     dev_index = local_rank % max(n_dev, 1) if world > 1 else 0       # one rank per GPU; the modulo only matters
@@ -309,7 +315,7 @@ def main():
     out = {
         'metric': 'train rays/sec (8192-ray batch, 160^3 grid)', 'value': value, 'unit': 'rays/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': f'cfg2 {args.workload}: {args.world}^3 fine grid, k0_dim 12 + rgbnet 3x128, '
                                f'{args.rays} rays/GPU x {M0 // args.rays} samples/ray '
                                f'(M_d={M_d}, M_k={M_k} per GPU per step), full train step',
