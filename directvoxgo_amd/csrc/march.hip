@@ -131,16 +131,26 @@ march_density_kernel(const float* __restrict__ rays_start, const float* __restri
       a = 1.0f - powf(1.0f + e, -P.interval);
       if (filt) keep = a > P.thres;
     }
-    // transmittance: T_before[lane] = Tc * prod_{l<lane} f_l, f = 1 - alpha + 1e-10 for kept samples
-    const float f = keep ? (float)(1.0 - (double)a + 1e-10) : 1.0f;
-    const float pincl = wave_prod_scan(f, lane);
-    float pexcl = __shfl_up(pincl, 1);
-    if (lane == 0) pexcl = 1.0f;
-    const float T_before = Tc * pexcl;
-    const float T_after = Tc * pincl;
-    const unsigned long long stop = __ballot(keep && ((double)T_after < 1e-3));
-    const int first = stop ? (__ffsll((long long)stop) - 1) : 63;
-    const bool valid2 = keep && (lane <= first);
+    // transmittance, in the reference's order and precision (K12, render_utils_kernel.cu:448-454):
+    //   T_cum = (float)((double)T_cum * (1. - alpha + 1e-10)), stop after the first sample with (double)T_cum < 1e-3.
+    // The double factor is lane-parallel; the float carry is walked over the KEPT lanes only (a dropped sample
+    // never enters compositing): each step is one exec-masked multiply on lane j and a v_readlane of the result,
+    // so T, the weights and every threshold decision are bit-identical to the serial code.
+    const double f = 1.0 - (double)a + 1e-10;
+    float T_before = 1.0f, T_after = 1.0f;
+    unsigned long long todo = __ballot(keep);
+    int stop_lane = -1;
+    while (todo) {
+      const int j = __ffsll((long long)todo) - 1;
+      todo &= todo - 1;
+      if (lane == j) { T_before = Tc; T_after = (float)((double)Tc * f); }
+      Tc = dvgo_readlane_f(T_after, j);
+      // (double)T < 1e-3  <=>  T < 1e-3f for floats (1e-3f is the float just above the double 1e-3); T >= 0, so the
+      // ordered-unsigned compare of the bit patterns is the same test and stays on the scalar unit
+      if (__float_as_uint(Tc) < 0x3A83126Fu) { stop_lane = j; break; }
+    }
+    const bool stop = stop_lane >= 0;
+    const bool valid2 = keep && (!stop || lane <= stop_lane);
     const float w = T_before * a;
     const bool keep3 = valid2 && (!filt || (w > P.thres));
     const unsigned long long m2 = __ballot(valid2), m3 = __ballot(keep3);
@@ -158,7 +168,6 @@ march_density_kernel(const float* __restrict__ rays_start, const float* __restri
     }
     c2 += __popcll(m2);
     c3 += __popcll(m3);
-    Tc = dvgo_readlane_f(T_after, first);
     if (stop) break;
   }
   if (lane == 0) {

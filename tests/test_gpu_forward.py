@@ -125,9 +125,10 @@ def test_forward_zero_rays_and_no_grad():
 
 @pytest.mark.parametrize('width,direct', [(32, False), (128, True)])
 def test_fused_equals_unfused_on_larger_scene(width, direct):
-    """A 48^3 scene with 2048 camera rays: fused and op-by-op HIP paths agree (the early-stop and
-    threshold decisions are taken on values that differ by float rounding only, so allow a handful
-    of samples to flip and compare per-ray results)."""
+    """A 48^3 scene with 2048 camera rays: the fused march carries the transmittance in the reference's order and
+    precision (render_utils_kernel.cu:448-454), so every index output and every per-sample forward value equals the
+    op-by-op HIP path (which is bit-exact against the oracle, test_gpu_ops.py) BIT FOR BIT; only sums whose order
+    differs (per-ray colour sum, atomically scattered gradients) carry a tolerance."""
     from directvoxgo_amd.dvgo import DirectVoxGO
     from directvoxgo_amd.scenes import synthetic_scene
     torch.manual_seed(0)
@@ -155,9 +156,10 @@ def test_fused_equals_unfused_on_larger_scene(width, direct):
     for k in (1, 2):      # the two fused variants differ by atomic summation order only
         assert (outs[True][k] - outs['separate'][k]).abs().max() <= 1e-5 * outs['separate'][k].abs().max()
     a, b = outs[True][0], outs[False][0]
-    assert abs(a['weights'].numel() - b['weights'].numel()) <= 4
+    assert torch.equal(a['ray_id'], b['ray_id'])                      # index outputs: exact
+    assert torch.equal(a['weights'], b['weights']) and torch.equal(a['raw_alpha'], b['raw_alpha'])
+    assert torch.equal(a['alphainv_last'], b['alphainv_last'])
     assert torch.allclose(a['rgb_marched'], b['rgb_marched'], atol=2e-5)
-    assert torch.allclose(a['alphainv_last'], b['alphainv_last'], atol=2e-5)
     assert torch.allclose(a['depth'], b['depth'], rtol=1e-4, atol=1e-2)
     for ga, gb in ((outs[True][1], outs[False][1]), (outs[True][2], outs[False][2])):
         denom = gb.abs().max()
