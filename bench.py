@@ -23,6 +23,7 @@ One JSON line on stdout (rank 0) with the contract's fields plus
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -38,7 +39,8 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/
 
 HOT_KERNELS = ['dvgo_sample_pts_prepare', 'dvgo_march_density', 'dvgo_exclusive_scan_i32', 'dvgo_march_gather',
                'dvgo_march_composite', 'dvgo_march_composite_bwd', 'dvgo_march_feat_bwd', 'dvgo_march_density_bwd',
-               'dvgo_grid_grad_split', 'dvgo_adam_rows', 'dvgo_adam_upd', 'dvgo_shade_fwd', 'dvgo_shade_bwd', 'dvgo_shade_wgrad']
+               'dvgo_grid_grad_split', 'dvgo_adam_rows', 'dvgo_adam_upd', 'dvgo_shade_fwd', 'dvgo_shade_bwd', 'dvgo_shade_wgrad',
+               'dvgo_brick_scan', 'dvgo_brick_accumulate']
 
 
 def algorithmic_bytes(name, N, M_d, M2, M_k, C, n_grid):
@@ -57,6 +59,11 @@ def algorithmic_bytes(name, N, M_d, M2, M_k, C, n_grid):
         'dvgo_grid_grad_split': None,                                       # per call: 64 B read + 52 B written per voxel
         'dvgo_adam_rows': None,                                             # per call: 64 B row + 6 x 52 B of p / m / v per voxel
         'dvgo_adam_upd': None,                                              # per call: 28 B / element (dense)
+        'dvgo_brick_scan': None,
+        # owner-computes scatter with the Adam update applied from the LDS tile: the scatter's algorithmic bytes
+        # (8 corner rows of C + 1 floats per sample + the sample's gradient row) + Adam's 6 x (C + 1) x 4 B
+        # (p, m, v read and written) per voxel
+        'dvgo_brick_accumulate': M_k * (8 * (C + 1) * 4 + (C + 1) * 4) + (n_grid // (C + 1)) * 6 * (C + 1) * 4,
         # colour head (row N3): MFMA-bound, bytes listed for completeness (features / activations in and out)
         'dvgo_shade_fwd': M_k * (C * 4 + 8 + 12 + 2 * 512),
         'dvgo_shade_bwd': M_k * (24 + 32 + 512 + C * 4),
@@ -165,10 +172,26 @@ def timed_region(step_fn, pool, steps, warmup, world, profile=True):
     return dt, prof
 
 
-def cpu_baseline(sc_cpu, m, rk, n_rays_total, sample_rays):
-    """The CPU oracle ("port": oracle/dvgo_oracle.c, scalar, 1 thread; MLP by torch CPU on 1 thread) on a
-    bounded sample: the first `sample_rays` rays of the same workload through the march forward +
-    backward, extrapolated to a full batch, plus one full Adam sweep."""
+def _cpu_info():
+    model = 'unknown'
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                model = line.split(':', 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count()
+    return model, usable
+
+
+def _c_port_baseline(sc_cpu, m, rk, n_rays_total, sample_rays):
+    """The scalar C oracle (oracle/dvgo_oracle.c, 1 thread; MLP by torch CPU on 1 thread) on a bounded sample: the
+    first `sample_rays` rays of the same workload through the march forward + backward, extrapolated to a full batch,
+    plus one full Adam sweep."""
     from oracle import oracle as O
     torch.set_num_threads(1)
     mn, mx = sc_cpu['xyz_min'].numpy(), sc_cpu['xyz_max'].numpy()
@@ -221,10 +244,99 @@ def cpu_baseline(sc_cpu, m, rk, n_rays_total, sample_rays):
     t_step = t_march * (n_rays_total / sample_rays) + t_adam
     return {'value': n_rays_total / t_step, 'unit': 'rays/s', 'cores': 1, 'kind': 'port',
             'sample': f'{sample_rays} of {n_rays_total} rays x {int(len(pts) / max(sample_rays, 1))} samples/ray through '
-                      f'oracle march fwd+bwd + torch-CPU rgbnet fwd+bwd on 1 thread ({t_march:.2f} s, extrapolated x'
+                      f'oracle/dvgo_oracle.c march fwd+bwd + torch-CPU rgbnet fwd+bwd on 1 thread ({t_march:.2f} s, extrapolated x'
                       f'{n_rays_total // sample_rays}) + one full oracle MaskedAdam sweep over {n_el} grid elements '
-                      f'({t_adam:.2f} s)',
-            'host_cpus': os.cpu_count()}
+                      f'({t_adam:.2f} s)'}
+
+
+def _torch_cpu_step(P, density, k0, rgbnet, viewfreq, rays, target, states, step_no, lrs, modes, perlr=None, w_ent=0.001,
+                    w_per=0.01):
+    """one full optimisation step of the pure-PyTorch restatement (oracle/torch_cpu.py): forward, loss of run.py:377-386,
+    autograd backward (F.grid_sample's scatter into dense zero-filled gradients), Adam over every grid element."""
+    from oracle import torch_cpu as TC
+    ro, rd, vd = rays
+    res = TC.render(density, k0, rgbnet, viewfreq, ro, rd, vd, P['xyz_min'], P['xyz_max'], P['near'], P['far'], P['stepdist'],
+                    P['n_samples'], P['act_shift'], P['interval'], P['thres'], 1.0, mask=P.get('mask'))
+    loss = TC.loss_fn(res, target, 1.0, w_ent, w_per)
+    params = [density, k0] + (list(rgbnet.parameters()) if rgbnet is not None else [])
+    grads = torch.autograd.grad(loss, params, allow_unused=True)
+    for i, (p, g) in enumerate(zip(params, grads)):
+        if g is None:
+            continue
+        mth, vth = states[i]
+        TC.adam_step(p.data, g, mth, vth, step_no, lrs[min(i, 2)], mode=modes[min(i, 2)], perlr=perlr if (i == 0 and modes[0] == 2) else None)
+    return int(res['weights'].numel())
+
+
+def cpu_baseline(sc_cpu, m, rk, n_rays_total, sample_rays):
+    """BASELINE.md section 3 on this host.  Primary entry: the pure-PyTorch restatement (oracle/torch_cpu.py) on all
+    usable host cores, config-2 roofline workload, a bounded sample of the batch (march part extrapolated, the Adam
+    sweep over all 53 M grid elements timed whole).  `config1`: BASELINE configs[0] (coarse ~100^3 grid, k0 = RGB,
+    1024 rays, per-voxel learning rate, full step) timed end to end.  `c_port_1_thread`: the scalar C oracle."""
+    import copy
+    from oracle import torch_cpu as TC
+    model, usable = _cpu_info()
+    threads = int(os.environ.get('DVGO_CPU_THREADS', '0')) or usable
+    torch.set_num_threads(threads)
+    out = {}
+    # ---------------- config 2, roofline case, `sample_rays` rays
+    n = min(sample_rays, n_rays_total)
+    density = sc_cpu['density'].clone().requires_grad_()
+    k0 = sc_cpu['k0'].contiguous().clone().requires_grad_()                # F.grid_sample wants [1,C,X,Y,Z] contiguous
+    rgbnet = copy.deepcopy(m.rgbnet).cpu()
+    P = dict(xyz_min=sc_cpu['xyz_min'], xyz_max=sc_cpu['xyz_max'], near=rk['near'], far=rk['far'],
+             stepdist=float(rk['stepsize'] * m.voxel_size), n_samples=int(sc_cpu.get('n_samples', 256)),
+             act_shift=float(m.act_shift), interval=float(rk['stepsize'] * m.voxel_size_ratio), thres=float(m.fast_color_thres))
+    params = [density, k0] + list(rgbnet.parameters())
+    states = [(torch.zeros_like(p), torch.zeros_like(p)) for p in params]
+    rays = tuple(sc_cpu[k][:n] for k in ('rays_o', 'rays_d', 'viewdirs'))
+    t0 = time.perf_counter()
+    M = _torch_cpu_step(P, density, k0, rgbnet, m.viewfreq.cpu(), rays, sc_cpu['target'][:n], states, 1, (0.1, 0.1, 1e-3),
+                        (1, 1, 0))
+    t_all = time.perf_counter() - t0
+    # the Adam sweep does not shrink with the sample: time it alone and extrapolate only the rest
+    g = torch.ones_like(k0)
+    t0 = time.perf_counter()
+    TC.adam_step(k0.data, g, *states[1], 2, 0.1, mode=1)
+    TC.adam_step(density.data, torch.ones_like(density), *states[0], 2, 0.1, mode=1)
+    t_adam = time.perf_counter() - t0
+    t_step = max(t_all - t_adam, 0.0) * (n_rays_total / n) + t_adam
+    out.update({'value': n_rays_total / t_step, 'unit': 'rays/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+                'cpu_model': model, 'host_cpus': os.cpu_count(), 'usable_cpus': usable,
+                'sample': f'pure-PyTorch restatement (oracle/torch_cpu.py: F.grid_sample + cumprod + index_add + torch MLP + Adam), '
+                          f'{n} of {n_rays_total} rays x {M // max(n, 1)} kept samples/ray, full step {t_all:.2f} s of which the '
+                          f'Adam sweep over all grid elements {t_adam:.2f} s; the rest extrapolated x{n_rays_total / n:g}'})
+    del density, k0, states, g
+    # ---------------- config 1: coarse stage on the CPU (configs/default.py:36-57,72-96)
+    try:
+        from directvoxgo_amd.scenes import synthetic_scene
+        sc1 = synthetic_scene(world=100, n_rays=1024, seed=777, device='cpu', k0_dim=3, alpha_init=1e-6, fast_color_thres=1e-7)
+        vs = float(((sc1['xyz_max'] - sc1['xyz_min']).prod() / 100 ** 3) ** (1 / 3))
+        d1 = sc1['density'].clone().requires_grad_(); c1 = sc1['k0'].clone().requires_grad_()
+        P1 = dict(xyz_min=sc1['xyz_min'], xyz_max=sc1['xyz_max'], near=2.0, far=6.0, stepdist=0.5 * vs,
+                  n_samples=int(np.linalg.norm(np.array([100, 100, 100]) + 1) / 0.5) + 1, act_shift=math.log(1 / (1 - 1e-6) - 1),
+                  interval=0.5, thres=1e-7)
+        st1 = [(torch.zeros_like(d1), torch.zeros_like(d1)), (torch.zeros_like(c1), torch.zeros_like(c1))]
+        perlr = torch.rand_like(d1)                                         # view-count learning rate (run.py:311-320)
+        rays1 = (sc1['rays_o'], sc1['rays_d'], sc1['viewdirs'])
+        _torch_cpu_step(P1, d1, c1, None, None, rays1, sc1['target'], st1, 1, (0.1, 0.1, 0), (2, 0, 0), perlr, 0.01, 0.1)   # warm-up
+        reps = 3
+        t0 = time.perf_counter()
+        for i in range(reps):
+            M1 = _torch_cpu_step(P1, d1, c1, None, None, rays1, sc1['target'], st1, 2 + i, (0.1, 0.1, 0), (2, 0, 0), perlr, 0.01, 0.1)
+        t1 = (time.perf_counter() - t0) / reps
+        out['config1'] = {'value': 1024 / t1, 'unit': 'rays/s', 'ms_per_step': t1 * 1e3, 'cores': torch.get_num_threads(),
+                          'workload': f'cfg1: coarse 100^3 grid, k0 = RGB (no MLP), 1024 rays x {M1 // 1024} kept samples/ray, '
+                                      f'per-voxel lr, full step (forward, loss, backward, Adam), mean of {reps}'}
+    except Exception as exc:                                                # the baseline must not take the bench line down
+        out['config1'] = {'error': repr(exc)}
+    # ---------------- the scalar C port, one thread
+    try:
+        out['c_port_1_thread'] = _c_port_baseline(sc_cpu, m, rk, n_rays_total, min(sample_rays, 1024))
+    except Exception as exc:
+        out['c_port_1_thread'] = {'error': repr(exc)}
+    torch.set_num_threads(threads)
+    return out
 
 
 def main():
@@ -240,7 +352,7 @@ def main():
                          "(BASELINE configs[2]: one 8192-ray batch sharded over 8 GPUs)")
     ap.add_argument('--no-secondary', action='store_true', help='skip the lego-like secondary measurement')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample-rays', type=int, default=4096)
+    ap.add_argument('--cpu-sample-rays', type=int, default=2048)
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend for N > 1 ('nccl' = RCCL on ROCm)")
     args = ap.parse_args()
 
@@ -295,10 +407,12 @@ def main():
             ab = (64 + 52) * m.density.numel()
         if name == 'dvgo_adam_rows':
             ab = (64 + 6 * 52) * m.density.numel()
+        if name == 'dvgo_brick_scan':
+            ab = 12 * ((args.world + 7) // 8) ** 3
         kernels[name] = {'launches': cnt, 'avg_ms': per_ms, 'alg_bytes': ab,
                          'GBps': ab / per_ms / 1e6, 'frac': ab / per_ms / 1e6 / HBM_PEAK_GBS}
     march = {k: v for k, v in kernels.items() if k in ('dvgo_march_gather', 'dvgo_march_feat_bwd', 'dvgo_march_density',
-                                                        'dvgo_march_density_bwd')}
+                                                        'dvgo_march_density_bwd', 'dvgo_brick_accumulate')}
     dom = max(march, key=lambda k: march[k]['avg_ms']) if march else None
     traffic = pmc_traffic(args.workload, args.world, args.rays)
     for k in kernels:

@@ -1,0 +1,308 @@
+// Owner-computes gradient scatter of the fused march backward: no float atomics, no zero-fill.
+//
+// Float atomics leave the chip as 64-byte memory-side requests at a fixed chip-wide rate (MI355X_MICROARCH "Global
+// float atomics", ~1.3 TB/s): the per-wavefront de-duplicating scatter of march.hip sits at 80 % of that cap and at a
+// third of the HBM roofline.  The grid-gradient of the reference (grid_sampler_3d_backward behind lib/dvgo.py:321,
+// 8*C atomics per sample) is a sum per VOXEL, so here a workgroup OWNS the voxels of one 8x8x8 brick:
+//
+//   count   march_density (forward) counts, per brick, the samples that touch one of its voxels
+//   scan    dvgo_brick_scan: exclusive offsets, fill cursors
+//   fill    march_density_bwd appends one 16-byte record {kept index, ray, step, density gradient} of every sample to
+//           the list of each brick it touches (a sample on a brick face is listed by up to 8 bricks: x1.42 on
+//           average)
+//   sum     brick_accumulate_kernel (this file): one workgroup per brick; per 256 list entries a counting sort of
+//           the (entry, corner) references by voxel in LDS (integer tickets only), then every thread sums the
+//           references of ITS two voxels x (C + 1) channels in registers.  The finished 512 x (C + 1) tile leaves
+//           through LDS as plain, coalesced stores -- either as the dense gradients (k0.grad channels-last,
+//           density.grad; untouched bricks are written as zeros, so no memset) or, when the training step owns the
+//           optimizer, consumed in place by the masked Adam update (adam_upd_kernel.cu:25-40) of the brick's
+//           parameters: the gradient then never exists in HBM.
+#include "common.h"
+
+// exclusive scan of the per-brick counts (single workgroup; nb is 8000 at 160^3, 32768 at 256^3)
+__global__ void __launch_bounds__(1024)
+brick_scan_kernel(const int32_t* __restrict__ cnt, int nb, int32_t* __restrict__ off, int32_t* __restrict__ cursor) {
+  __shared__ int s_wave[16];
+  __shared__ int s_carry;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_carry = 0;
+  __syncthreads();
+  for (int base = 0; base < nb; base += 1024) {
+    const int i = base + tid;
+    const int c = (i < nb) ? cnt[i] : 0;
+    int inc = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(inc, d);
+      if (lane >= d) inc += o;
+    }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    int wbase = s_carry;
+    for (int w = 0; w < wave; ++w) wbase += s_wave[w];
+    const int ex = wbase + inc - c;
+    if (i < nb) { off[i] = ex; cursor[i] = ex; }
+    __syncthreads();
+    if (tid == 1023) s_carry = ex + c;
+    __syncthreads();
+  }
+  if (tid == 0) off[nb] = s_carry;
+}
+
+struct BrickAdam {
+  float *pk, *mk, *vk, *pd, *md, *vd;
+  float ss_k, ss_d, beta1, beta2, eps;
+  int masked_k, masked_d;
+};
+
+struct BrickGeom {
+  int X, Y, Z, BX, BY, BZ, nb;
+  float mnx, mny, mnz, mxx, mxy, mxz, stepdist;      // sample positions are rebuilt from (ray, step) as in the forward
+};
+
+template <int MODE>
+__device__ __forceinline__ void adam4(float4& p, const float4 g, float4& m, float4& v, float ss, float b1, float b2, float eps) {
+  adam_one<MODE>(p.x, g.x, m.x, v.x, 0.f, ss, b1, b2, eps);
+  adam_one<MODE>(p.y, g.y, m.y, v.y, 0.f, ss, b1, b2, eps);
+  adam_one<MODE>(p.z, g.z, m.z, v.z, 0.f, ss, b1, b2, eps);
+  adam_one<MODE>(p.w, g.w, m.w, v.w, 0.f, ss, b1, b2, eps);
+}
+
+// ADAM: 0 = write the dense gradients, 1 = apply the (masked) Adam update in place
+template <int C, int ADAM>
+__global__ void __launch_bounds__(256)
+brick_accumulate_kernel(const int32_t* __restrict__ off, const int4* __restrict__ recs,
+                        const float* __restrict__ rays_start, const float* __restrict__ rays_dir,
+                        const float* __restrict__ g_feat, BrickGeom G, float* __restrict__ grad_k0,
+                        float* __restrict__ grad_density, BrickAdam A) {
+  constexpr int CE = C + 1;                      // the density gradient rides as channel C
+  constexpr int G4 = ((CE + 3) / 4) | 1;         // staged gradient rows: an ODD number of 16-byte pieces, so that the
+  constexpr int GS = 4 * G4;                     //   ds_read_b128 of 16 lanes with different rows spread over the banks
+  constexpr int TS = (CE + 3) & ~3;              // row stride of the finished tile
+  struct Sort {
+    int cnt[512];                                // tickets per voxel, then the voxel's first reference
+    int wsum[4];
+    float2 refs[2048];                           // {weight, entry} sorted by voxel
+    float g[256][GS];                            // the chunk's gradient rows
+  };
+  union Lds {
+    Sort s;
+    float tile[512][TS];
+  };
+  __shared__ __attribute__((aligned(16))) Lds u;
+  static_assert(sizeof(Lds) <= 40960, "4 workgroups per CU");
+
+  // blocks b and b + 8 share an XCD (round-robin dispatch): give each XCD a contiguous range of bricks, so that the
+  // up-to-8 bricks listing one sample read its gradient row through the same L2
+  const int per = (G.nb + 7) >> 3;
+  const int b = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+  if (b >= G.nb) return;
+  const int bz = b % G.BZ, by = (b / G.BZ) % G.BY, bx = b / (G.BZ * G.BY);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lo = off[b], n = off[b + 1] - lo;
+  if (ADAM && n == 0) return;                    // untouched brick: nothing to update
+
+  float acc0[CE], acc1[CE];
+#pragma unroll
+  for (int c = 0; c < CE; ++c) { acc0[c] = 0.f; acc1[c] = 0.f; }
+
+  if (n > 0) {
+    u.s.cnt[2 * tid] = 0;
+    u.s.cnt[2 * tid + 1] = 0;
+    __syncthreads();
+  }
+  for (int base = 0; base < n; base += 256) {
+    const int e = base + tid;
+    int rowc[8], tk[8];
+    float wc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { rowc[q] = -1; tk[q] = 0; wc[q] = 0.f; }
+    if (e < n) {
+      const int4 rec = recs[lo + e];                        // {kept index or -1, ray, step, density gradient}
+      float* gp = u.s.g[tid];
+      if (rec.x >= 0) {
+        const float* src = g_feat + (int64_t)rec.x * C;
+        if constexpr (C % 4 == 0) {
+#pragma unroll
+          for (int c = 0; c < C / 4; ++c) reinterpret_cast<float4*>(gp)[c] = reinterpret_cast<const float4*>(src)[c];
+        } else {
+#pragma unroll
+          for (int c = 0; c < C; ++c) gp[c] = src[c];
+        }
+      } else {                                   // passed the alpha filter only: no feature gradient
+#pragma unroll
+        for (int c = 0; c < C; ++c) gp[c] = 0.f;
+      }
+      gp[C] = __int_as_float(rec.w);
+      float px, py, pz;
+      march_pos(rays_start, rays_dir, rec.y, G.stepdist, rec.z, px, py, pz);
+      const TriSetup t = dvgo_tri_setup(px, py, pz, G.mnx, G.mny, G.mnz, G.mxx, G.mxy, G.mxz, G.X, G.Y, G.Z);
+      const int li = t.i0 - (bx << DVGO_BRICK_LOG), lj = t.j0 - (by << DVGO_BRICK_LOG), lk = t.k0 - (bz << DVGO_BRICK_LOG);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int di = li + ((q >> 2) & 1), dj = lj + ((q >> 1) & 1), dk = lk + (q & 1);
+        const bool mine = ((unsigned)di < DVGO_BRICK) & ((unsigned)dj < DVGO_BRICK) & ((unsigned)dk < DVGO_BRICK);
+        if (mine && dvgo_tri_inb(t, q, G.X, G.Y, G.Z)) {
+          rowc[q] = (di << (2 * DVGO_BRICK_LOG)) | (dj << DVGO_BRICK_LOG) | dk;
+          wc[q] = dvgo_tri_weight(t, q);
+          tk[q] = atomicAdd(&u.s.cnt[rowc[q]], 1);
+        }
+      }
+    }
+    __syncthreads();
+    // exclusive scan of the 512 counters: thread t owns voxels 2t and 2t + 1 from here on
+    const int c0 = u.s.cnt[2 * tid], c1 = u.s.cnt[2 * tid + 1];
+    const int s = c0 + c1;
+    int inc = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(inc, d);
+      if (lane >= d) inc += o;
+    }
+    if (lane == 63) u.s.wsum[wave] = inc;
+    __syncthreads();
+    int o0 = inc - s;
+    for (int w = 0; w < wave; ++w) o0 += u.s.wsum[w];
+    const int o1 = o0 + c0;
+    u.s.cnt[2 * tid] = o0;
+    u.s.cnt[2 * tid + 1] = o1;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (rowc[q] >= 0) u.s.refs[u.s.cnt[rowc[q]] + tk[q]] = make_float2(wc[q], __int_as_float(tid));
+    __syncthreads();
+    for (int k = 0; k < c0; ++k) {
+      const float2 r = u.s.refs[o0 + k];
+      const float* g = u.s.g[__float_as_int(r.y)];
+#pragma unroll
+      for (int c = 0; c < CE; ++c) acc0[c] = fmaf(r.x, g[c], acc0[c]);
+    }
+    for (int k = 0; k < c1; ++k) {
+      const float2 r = u.s.refs[o1 + k];
+      const float* g = u.s.g[__float_as_int(r.y)];
+#pragma unroll
+      for (int c = 0; c < CE; ++c) acc1[c] = fmaf(r.x, g[c], acc1[c]);
+    }
+    u.s.cnt[2 * tid] = 0;
+    u.s.cnt[2 * tid + 1] = 0;
+    __syncthreads();
+  }
+
+  // the finished tile, voxel-major, through LDS so that the global accesses below are coalesced
+#pragma unroll
+  for (int c = 0; c < TS; ++c) {
+    u.tile[2 * tid][c] = (c < CE) ? acc0[c] : 0.f;
+    u.tile[2 * tid + 1][c] = (c < CE) ? acc1[c] : 0.f;
+  }
+  __syncthreads();
+
+  const int x0 = bx << DVGO_BRICK_LOG, y0 = by << DVGO_BRICK_LOG, z0 = bz << DVGO_BRICK_LOG;
+  if constexpr (C == 12) {
+    // 4 lanes per voxel: three float4 of features + the density scalar; 8 voxels in z = 384 contiguous bytes of k0
+    for (int idx = tid; idx < 512 * 4; idx += 256) {
+      const int row = idx >> 2, q = idx & 3;
+      const int gi = x0 + (row >> 6), gj = y0 + ((row >> 3) & 7), gk = z0 + (row & 7);
+      if (gi >= G.X || gj >= G.Y || gk >= G.Z) continue;
+      const int64_t vox = ((int64_t)gi * G.Y + gj) * G.Z + gk;
+      const float4 g = reinterpret_cast<const float4*>(u.tile[row])[q];
+      if (!ADAM) {
+        if (q < 3) reinterpret_cast<float4*>(grad_k0)[vox * 3 + q] = g;
+        else grad_density[vox] = g.x;
+      } else if (q < 3) {
+        if (A.masked_k && g.x == 0.f && g.y == 0.f && g.z == 0.f && g.w == 0.f) continue;
+        const int64_t i = vox * 3 + q;
+        float4 p = reinterpret_cast<float4*>(A.pk)[i], m = reinterpret_cast<float4*>(A.mk)[i], v = reinterpret_cast<float4*>(A.vk)[i];
+        if (A.masked_k) adam4<1>(p, g, m, v, A.ss_k, A.beta1, A.beta2, A.eps);
+        else adam4<0>(p, g, m, v, A.ss_k, A.beta1, A.beta2, A.eps);
+        reinterpret_cast<float4*>(A.pk)[i] = p;
+        reinterpret_cast<float4*>(A.mk)[i] = m;
+        reinterpret_cast<float4*>(A.vk)[i] = v;
+      } else {
+        if (A.masked_d) adam_one<1>(A.pd[vox], g.x, A.md[vox], A.vd[vox], 0.f, A.ss_d, A.beta1, A.beta2, A.eps);
+        else adam_one<0>(A.pd[vox], g.x, A.md[vox], A.vd[vox], 0.f, A.ss_d, A.beta1, A.beta2, A.eps);
+      }
+    }
+  } else {
+    for (int idx = tid; idx < 512 * CE; idx += 256) {
+      const int row = idx / CE, c = idx - row * CE;
+      const int gi = x0 + (row >> 6), gj = y0 + ((row >> 3) & 7), gk = z0 + (row & 7);
+      if (gi >= G.X || gj >= G.Y || gk >= G.Z) continue;
+      const int64_t vox = ((int64_t)gi * G.Y + gj) * G.Z + gk;
+      const float g = u.tile[row][c];
+      if (!ADAM) {
+        if (c < C) grad_k0[vox * C + c] = g;
+        else grad_density[vox] = g;
+      } else if (c < C) {
+        const int64_t i = vox * C + c;
+        if (A.masked_k) adam_one<1>(A.pk[i], g, A.mk[i], A.vk[i], 0.f, A.ss_k, A.beta1, A.beta2, A.eps);
+        else adam_one<0>(A.pk[i], g, A.mk[i], A.vk[i], 0.f, A.ss_k, A.beta1, A.beta2, A.eps);
+      } else {
+        if (A.masked_d) adam_one<1>(A.pd[vox], g, A.md[vox], A.vd[vox], 0.f, A.ss_d, A.beta1, A.beta2, A.eps);
+        else adam_one<0>(A.pd[vox], g, A.md[vox], A.vd[vox], 0.f, A.ss_d, A.beta1, A.beta2, A.eps);
+      }
+    }
+  }
+}
+
+extern "C" {
+
+int dvgo_n_bricks(int X, int Y, int Z) {
+  if (X <= 0 || Y <= 0 || Z <= 0) return DVGO_EINVAL;
+  const int64_t nb = (int64_t)((X + DVGO_BRICK - 1) >> DVGO_BRICK_LOG) * ((Y + DVGO_BRICK - 1) >> DVGO_BRICK_LOG) *
+                     ((Z + DVGO_BRICK - 1) >> DVGO_BRICK_LOG);
+  return nb < ((int64_t)1 << 30) ? (int)nb : DVGO_ERANGE;
+}
+
+int dvgo_brick_scan(const int32_t* brick_cnt, int n_bricks, int32_t* brick_off, int32_t* brick_cursor, void* stream) {
+  if (n_bricks < 0) return DVGO_EINVAL;
+  if (!brick_cnt || !brick_off || !brick_cursor) return DVGO_EINVAL;
+  brick_scan_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(brick_cnt, n_bricks, brick_off, brick_cursor);
+  DVGO_LAUNCH_CHECK();
+  return 0;
+}
+
+int dvgo_brick_accumulate(const int32_t* brick_off, const void* recs, const float* rays_start, const float* rays_dir,
+                          float stepdist, const float* xyz_min, const float* xyz_max, const float* grad_feat,
+                          int C, int X, int Y, int Z, float* grad_k0, float* grad_density,
+                          float* p_k0, float* m_k0, float* v_k0, float step_size_k0, int masked_k0,
+                          float* p_density, float* m_density, float* v_density, float step_size_density,
+                          int masked_density, float beta1, float beta2, float eps, void* stream) {
+  const int nb = dvgo_n_bricks(X, Y, Z);
+  if (nb < 0) return nb;
+  const bool adam = p_k0 != nullptr;
+  if (!brick_off || !recs || !rays_start || !rays_dir || !xyz_min || !xyz_max) return DVGO_EINVAL;
+  if (adam && (!m_k0 || !v_k0 || !p_density || !m_density || !v_density)) return DVGO_EINVAL;
+  if (!adam && (!grad_k0 || !grad_density)) return DVGO_EINVAL;
+  if (C == 12 && ((((uintptr_t)grad_feat | (uintptr_t)grad_k0 | (uintptr_t)p_k0 | (uintptr_t)m_k0 | (uintptr_t)v_k0) & 15) != 0))
+    return DVGO_EINVAL;
+  BrickGeom G;
+  G.X = X; G.Y = Y; G.Z = Z;
+  G.BX = (X + DVGO_BRICK - 1) >> DVGO_BRICK_LOG; G.BY = (Y + DVGO_BRICK - 1) >> DVGO_BRICK_LOG; G.BZ = (Z + DVGO_BRICK - 1) >> DVGO_BRICK_LOG;
+  G.nb = nb;
+  G.mnx = xyz_min[0]; G.mny = xyz_min[1]; G.mnz = xyz_min[2];
+  G.mxx = xyz_max[0]; G.mxy = xyz_max[1]; G.mxz = xyz_max[2];
+  G.stepdist = stepdist;
+  BrickAdam A;
+  A.pk = p_k0; A.mk = m_k0; A.vk = v_k0; A.pd = p_density; A.md = m_density; A.vd = v_density;
+  A.ss_k = step_size_k0; A.ss_d = step_size_density; A.beta1 = beta1; A.beta2 = beta2; A.eps = eps;
+  A.masked_k = masked_k0; A.masked_d = masked_density;
+  const int blocks = ((nb + 7) >> 3) << 3;
+  hipStream_t s = (hipStream_t)stream;
+#define DVGO_BRICK_ACC(CC)                                                                                        \
+  do {                                                                                                            \
+    if (adam) brick_accumulate_kernel<CC, 1><<<blocks, 256, 0, s>>>(brick_off, (const int4*)recs, rays_start, rays_dir, \
+                                                                     grad_feat, G, grad_k0, grad_density, A);       \
+    else brick_accumulate_kernel<CC, 0><<<blocks, 256, 0, s>>>(brick_off, (const int4*)recs, rays_start, rays_dir,  \
+                                                                grad_feat, G, grad_k0, grad_density, A);            \
+  } while (0)
+  if (C == 12) DVGO_BRICK_ACC(12);
+  else if (C == 9) DVGO_BRICK_ACC(9);
+  else if (C == 3) DVGO_BRICK_ACC(3);
+  else if (C == 4) DVGO_BRICK_ACC(4);
+  else return DVGO_ERANGE;
+#undef DVGO_BRICK_ACC
+  DVGO_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // extern "C"

@@ -23,20 +23,6 @@ __device__ __forceinline__ unsigned long long lanemask_lt(int lane) {
   return (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 }
 
-// distance of sample `step` along its ray:
-//   K6 (render_utils_kernel.cu:178)  stepdist * i_step          -- rays_start / unit rays_dir
-//   K7 (render_utils_kernel.cu:254)  (float)i_step / (N_samples - 1)  -- rays_o / un-normalised rays_d
-__device__ __forceinline__ float march_dist(float stepdist, int step) {
-  return (stepdist > 0.0f) ? stepdist * (float)step : ((float)step) / (-stepdist);
-}
-
-__device__ __forceinline__ void march_pos(const float* __restrict__ start, const float* __restrict__ dir, int64_t r,
-                                          float stepdist, int step, float& px, float& py, float& pz) {
-  const float dist = march_dist(stepdist, step);
-  px = fmaf(dir[3 * r + 0], dist, start[3 * r + 0]);
-  py = fmaf(dir[3 * r + 1], dist, start[3 * r + 1]);
-  pz = fmaf(dir[3 * r + 2], dist, start[3 * r + 2]);
-}
 
 // inclusive product scan across the wave
 __device__ __forceinline__ float wave_prod_scan(float v, int lane) {
@@ -82,6 +68,83 @@ struct MarchParams {
   float act_shift, interval, thres;
 };
 
+// ----------------------------------------------------------------------------------
+// Brick lists (brick.hip): every sample that entered compositing is listed by each 8x8x8 brick that holds one of
+// its 8 corner voxels (1 brick for 2/3 of the samples, up to 8 on brick faces / edges / corners).  The same routine
+// counts (forward) and fills (backward), so both see the same (sample, brick) incidences.
+// The 64 lanes of a chunk are consecutive steps of one ray and touch only a few dozen distinct bricks, so the wave
+// first DISCOVERS the distinct bricks with ballots only -- pick the first lane with an unlisted incidence, broadcast
+// its brick, ballot the lanes that touch it; lane #i remembers brick #i and its incidence count, every touching lane
+// remembers (i, its rank) -- then ONE atomic wave-instruction counts / reserves slots for all bricks of the chunk
+// (lane i for brick i), and the records go out.  One atomic round trip per chunk: per-incidence atomics on the 8000
+// counters cost 75 us per pass at 2 M samples, one returning atomic per distinct brick 87 us (a serial chain of
+// round trips).
+//   FILL = false : cur = per-brick counters
+//   FILL = true  : cur = per-brick fill cursors (start at the brick's offset); writes recs[slot] = rec
+// Must be called by all 64 lanes.
+// ----------------------------------------------------------------------------------
+template <bool FILL>
+__device__ __forceinline__ void brick_emit(bool act, int i0, int j0, int k0, int X, int Y, int Z, int lane,
+                                           int32_t* __restrict__ cur, int4* __restrict__ recs, const int4 rec) {
+  const int BY = (Y + DVGO_BRICK - 1) >> DVGO_BRICK_LOG, BZ = (Z + DVGO_BRICK - 1) >> DVGO_BRICK_LOG;
+  int bx0 = 0, bx1 = 0, by0 = 0, by1 = 0, bz0 = 0, bz1 = 0, nx = 0, ny = 0, nz = 0;
+  if (act) {
+    nx = dvgo_brick_axis(i0, X, bx0, bx1);
+    ny = dvgo_brick_axis(j0, Y, by0, by1);
+    nz = dvgo_brick_axis(k0, Z, bz0, bz1);
+  }
+  // incidence e = (a * ny + b) * nz + c, a < nx, b < ny, c < nz; bit e of `pending` = not listed yet
+  unsigned pending = (act && nx > 0 && ny > 0 && nz > 0) ? ((1u << (nx * ny * nz)) - 1u) : 0u;
+  const unsigned long long lt = lanemask_lt(lane);
+  while (__ballot(pending != 0u)) {
+    // ---- discover up to 64 distinct bricks
+    int it = 0, my_id = 0, my_cnt = 0;
+    unsigned round = 0u;                               // incidences listed in this round
+    unsigned long long iters = 0ull, ranks = 0ull;     // 8 bits per incidence: brick number in the round / rank in brick
+    for (;;) {
+      const unsigned long long bal = __ballot(pending != 0u);
+      if (!bal || it == 64) break;
+      const int leader = __ffsll((long long)bal) - 1;
+      const int e = __ffs((int)pending) - 1;                  // (garbage on lanes without pending work; never the leader)
+      const int c = (nz == 2) ? (e & 1) : 0, ab = (nz == 2) ? (e >> 1) : e;          // nx, ny, nz are 1 or 2
+      const int b = (ny == 2) ? (ab & 1) : 0, a = (ny == 2) ? (ab >> 1) : ab;
+      const int mine = ((a ? bx1 : bx0) << 20) | ((b ? by1 : by0) << 10) | (c ? bz1 : bz0);
+      const int Xp = __builtin_amdgcn_readlane(mine, leader);
+      const int Xx = Xp >> 20, Xy = (Xp >> 10) & 1023, Xz = Xp & 1023;
+      const int ma = (bx0 == Xx) ? 0 : ((nx == 2 && bx1 == Xx) ? 1 : -1);
+      const int mb = (by0 == Xy) ? 0 : ((ny == 2 && by1 == Xy) ? 1 : -1);
+      const int mc = (bz0 == Xz) ? 0 : ((nz == 2 && bz1 == Xz) ? 1 : -1);
+      const bool touch = (pending != 0u) && ma >= 0 && mb >= 0 && mc >= 0;
+      const unsigned long long m = __ballot(touch);
+      if (lane == it) { my_id = (Xx * BY + Xy) * BZ + Xz; my_cnt = __popcll(m); }
+      if (touch) {
+        const int em = (((ma << (ny - 1)) + mb) << (nz - 1)) + mc;
+        pending &= ~(1u << em);
+        round |= 1u << em;
+        iters |= (unsigned long long)it << (8 * em);
+        ranks |= (unsigned long long)__popcll(m & lt) << (8 * em);
+      }
+      ++it;
+    }
+    // ---- one atomic wave-instruction for all bricks of the round
+    int base = 0;
+    if (lane < it) {
+      if (FILL) base = atomicAdd(&cur[my_id], my_cnt);
+      else atomicAdd(&cur[my_id], my_cnt);
+    }
+    if (FILL) {
+#pragma unroll
+      for (int em = 0; em < 8; ++em) {
+        const bool have = (round >> em) & 1u;
+        if (!__ballot(have)) continue;
+        const int src = (int)((iters >> (8 * em)) & 255ull);
+        const int bs = __shfl(base, src);
+        if (have) recs[bs + (int)((ranks >> (8 * em)) & 255ull)] = rec;
+      }
+    }
+  }
+}
+
 __global__ void __launch_bounds__(DVGO_BLOCK)
 march_density_kernel(const float* __restrict__ rays_start, const float* __restrict__ rays_dir,
                      const int64_t* __restrict__ n_steps, const int64_t* __restrict__ cum,
@@ -89,7 +152,7 @@ march_density_kernel(const float* __restrict__ rays_start, const float* __restri
                      const float* __restrict__ density, MarchParams P,
                      dvgo_rec2_t* __restrict__ rec2, dvgo_rec3_t* __restrict__ rec3,
                      int32_t* __restrict__ n2, int32_t* __restrict__ n3,
-                     float* __restrict__ alphainv_last) {
+                     float* __restrict__ alphainv_last, int32_t* __restrict__ brick_cnt) {
   const int64_t ray = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   if (ray >= n_rays) return;
@@ -116,8 +179,10 @@ march_density_kernel(const float* __restrict__ rays_start, const float* __restri
       if (keep) keep = mask[((int64_t)i * P.mY + j) * P.mZ + k] != 0;
     }
     float e = 0.f, a = 0.f;
+    TriSetup t;
+    t.i0 = t.j0 = t.k0 = 0;
     if (keep) {
-      const TriSetup t = dvgo_tri_setup(px, py, pz, P.mnx, P.mny, P.mnz, P.mxx, P.mxy, P.mxz, P.X, P.Y, P.Z);
+      t = dvgo_tri_setup(px, py, pz, P.mnx, P.mny, P.mnz, P.mxx, P.mxy, P.mxz, P.X, P.Y, P.Z);
       float d = 0.f;
 #pragma unroll
       for (int n = 0; n < 8; ++n) {
@@ -168,6 +233,7 @@ march_density_kernel(const float* __restrict__ rays_start, const float* __restri
     }
     c2 += __popcll(m2);
     c3 += __popcll(m3);
+    if (brick_cnt != nullptr) brick_emit<false>(valid2, t.i0, t.j0, t.k0, P.X, P.Y, P.Z, lane, brick_cnt, nullptr, make_int4(0, 0, 0, 0));
     if (stop) break;
   }
   if (lane == 0) {
@@ -554,7 +620,10 @@ march_density_bwd_kernel(const dvgo_rec2_t* __restrict__ rec2, const int32_t* __
                          const float* __restrict__ grad_weights, const float* __restrict__ grad_last,
                          float* __restrict__ grad_density, int64_t gstride /* elements between voxels */,
                          float* __restrict__ grad_kept /* [M3] or null: kept samples hand their gradient to the
-                                                          feature scatter instead of scattering it here */) {
+                                                          feature scatter instead of scattering it here */,
+                         int32_t* __restrict__ brick_cursor /* null, or: no scatter here at all -- every sample is
+                                                               appended to the brick lists (brick.hip) */,
+                         int4* __restrict__ brick_recs) {
   constexpr int H = 512;
   __shared__ int s_keys[DEDUP ? 4 : 1][DEDUP ? H : 1];
   __shared__ float s_vals[DEDUP ? 4 : 1][DEDUP ? H : 1];
@@ -596,6 +665,9 @@ march_density_bwd_kernel(const dvgo_rec2_t* __restrict__ rec2, const int32_t* __
     const float suffix = wave_suffix_excl(gw * w, lane, total);   // inactive lanes contribute 0
     const float my_acc = acc + suffix;
     acc += total;
+    float g_d = 0.0f;
+    TriSetup t;
+    t.i0 = t.j0 = t.k0 = 0; t.gx = t.gy = t.gz = 0.f;
     if (act) {
       const float gt = gw * rec.T;
       const float one_minus = 1.0f - rec.alpha;
@@ -603,10 +675,16 @@ march_density_bwd_kernel(const dvgo_rec2_t* __restrict__ rec2, const int32_t* __
       double v = fmin((double)rec.exp_d, 1e10) * (double)powf(1.0f + rec.exp_d, -P.interval - 1.0f);
       v = v * (double)P.interval;
       v = v * (double)g_alpha;
-      const float g_d = (float)v;
+      g_d = (float)v;
       const float dist = march_dist(P.stepdist, step);
       const float px = fmaf(dx, dist, sx), py = fmaf(dy, dist, sy), pz = fmaf(dz, dist, sz);
-      const TriSetup t = dvgo_tri_setup(px, py, pz, P.mnx, P.mny, P.mnz, P.mxx, P.mxy, P.mxz, P.X, P.Y, P.Z);
+      t = dvgo_tri_setup(px, py, pz, P.mnx, P.mny, P.mnz, P.mxx, P.mxy, P.mxz, P.X, P.Y, P.Z);
+    }
+    if (brick_cursor != nullptr) {
+      // record = {kept index in the M3 order or -1, ray, step, density gradient}: 16 bytes, one store
+      brick_emit<true>(act, t.i0, t.j0, t.k0, P.X, P.Y, P.Z, lane, brick_cursor, brick_recs,
+                       make_int4(flag ? (int)(o3 + rank) : -1, (int)ray, step, __float_as_int(g_d)));
+    } else if (act) {
       if (grad_kept != nullptr && flag) grad_kept[o3 + rank] = g_d;
       else if (g_d != 0.0f) {
 #pragma unroll
@@ -681,7 +759,7 @@ int dvgo_march_density(const float* rays_start, const float* rays_dir, const int
                        const float* xyz2ijk_scale, const float* xyz2ijk_shift, const float* density,
                        int X, int Y, int Z, float act_shift, float interval, float fast_color_thres,
                        dvgo_rec2_t* rec2, dvgo_rec3_t* rec3, int32_t* n2, int32_t* n3,
-                       float* alphainv_last, void* stream) {
+                       float* alphainv_last, int32_t* brick_cnt, void* stream) {
   if (n_rays < 0 || X <= 0 || Y <= 0 || Z <= 0) return DVGO_EINVAL;
   if (n_rays == 0) return 0;
   if (!rays_start || !rays_dir || !n_steps || !xyz_min || !xyz_max || !density ||
@@ -694,7 +772,7 @@ int dvgo_march_density(const float* rays_start, const float* rays_dir, const int
                                     X, Y, Z, act_shift, interval, fast_color_thres);
   march_density_kernel<<<dvgo_blocks(n_rays * 64, DVGO_BLOCK), DVGO_BLOCK, 0, (hipStream_t)stream>>>(
       rays_start, rays_dir, n_steps, n_steps_cumsum, rec_stride, n_rays, mask, density, P, rec2, rec3, n2, n3,
-      alphainv_last);
+      alphainv_last, brick_cnt);
   DVGO_LAUNCH_CHECK();
   return 0;
 }
@@ -854,24 +932,26 @@ int dvgo_march_density_bwd(const dvgo_rec2_t* rec2, const int32_t* n2, const int
                            const float* rays_start, const float* rays_dir, float stepdist,
                            const float* xyz_min, const float* xyz_max, const float* alphainv_last,
                            float interval, const float* grad_weights, const float* grad_last, int X,
-                           int Y, int Z, float* grad_density, int64_t grad_stride, float* grad_kept, void* stream) {
+                           int Y, int Z, float* grad_density, int64_t grad_stride, float* grad_kept,
+                           int32_t* brick_cursor, void* brick_recs, void* stream) {
   if (n_rays < 0 || X <= 0 || Y <= 0 || Z <= 0) return DVGO_EINVAL;
   if (n_rays == 0) return 0;
   if (!rec2 || !n2 || !n_steps || !off3 || !rays_start || !rays_dir || !xyz_min ||
-      !xyz_max || !alphainv_last || !grad_density)
+      !xyz_max || !alphainv_last || (!grad_density && !brick_cursor))
     return DVGO_EINVAL;       // grad_weights may be NULL when M3 == 0 (it is only read for flagged samples)
-  if ((!n_steps_cumsum && rec_stride <= 0) || grad_stride <= 0) return DVGO_EINVAL;
+  if (brick_cursor && !brick_recs) return DVGO_EINVAL;
+  if ((!n_steps_cumsum && rec_stride <= 0) || (!brick_cursor && grad_stride <= 0)) return DVGO_EINVAL;
   if (!dvgo_fits(n_rays * 64)) return DVGO_ERANGE;
   const MarchParams P = make_params(xyz_min, xyz_max, stepdist, nullptr, nullptr, 0, 0, 0, X, Y, Z, 0.f,
                                     interval, 0.f);
-  if (g_tuning[DVGO_TUNE_DENSITY_BWD] == 1 && (int64_t)X * Y * Z < ((int64_t)1 << 31))
+  if (!brick_cursor && g_tuning[DVGO_TUNE_DENSITY_BWD] == 1 && (int64_t)X * Y * Z < ((int64_t)1 << 31))
     march_density_bwd_kernel<true><<<dvgo_blocks(n_rays * 64, DVGO_BLOCK), DVGO_BLOCK, 0, (hipStream_t)stream>>>(
         rec2, n2, n_steps, n_steps_cumsum, rec_stride, off3, n_rays, rays_start, rays_dir, P, alphainv_last,
-        grad_weights, grad_last, grad_density, grad_stride, grad_kept);
+        grad_weights, grad_last, grad_density, grad_stride, grad_kept, nullptr, nullptr);
   else
     march_density_bwd_kernel<false><<<dvgo_blocks(n_rays * 64, DVGO_BLOCK), DVGO_BLOCK, 0, (hipStream_t)stream>>>(
         rec2, n2, n_steps, n_steps_cumsum, rec_stride, off3, n_rays, rays_start, rays_dir, P, alphainv_last,
-        grad_weights, grad_last, grad_density, grad_stride, grad_kept);
+        grad_weights, grad_last, grad_density, grad_stride, grad_kept, brick_cursor, (int4*)brick_recs);
   DVGO_LAUNCH_CHECK();
   return 0;
 }

@@ -4,16 +4,6 @@
 //                      /root/reference/lib/cuda/total_variation_kernel.cu:13-35.
 #include "common.h"
 
-template <int MODE>   // 0 plain, 1 masked (skip grad == 0), 2 per-voxel lr
-__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float perlr,
-                                         float step_size, float beta1, float beta2, float eps) {
-  if (MODE == 1 && g == 0.0f) return;
-  m = fmaf(beta1, m, (1.0f - beta1) * g);
-  v = fmaf(beta2, v, ((1.0f - beta2) * g) * g);
-  const float ss = (MODE == 2) ? step_size * perlr : step_size;
-  p = p - (ss * m) / (sqrtf(v) + eps);
-}
-
 template <int MODE>
 __global__ void __launch_bounds__(DVGO_BLOCK)
 adam_kernel(float* __restrict__ param, const float* __restrict__ grad, float* __restrict__ exp_avg,

@@ -14,14 +14,14 @@ The fork-specific LIIF / positional-encoding experiments of the reference model
 (implicit_voxel_feat, posbase_pe, rgbnet_full_implicit; lib/dvgo.py:40-41,100-122,329-410) are
 outside the north-star path and raise NotImplementedError.
 """
-import time
-
 import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import _lib as L
 from . import render_utils as render_utils_hip
+from ._lib import _flt, _i64, _int, f3, ptr, stream_of
 from .fused import MarchConfig, composite, composite_depth, fused_hit, fused_march
 from .ops import Alphas2Weights, MaskCache, Raw2Alpha, grid_sample, segment_coo, total_variation_add_grad
 from .shade import shade, viewdir_embed
@@ -190,12 +190,16 @@ class DirectVoxGO(nn.Module):
     # ------------------------------------------------------------------ grid maintenance (N4)
     @torch.no_grad()
     def maskout_near_cam_vox(self, cam_o, near):
-        """lib/dvgo.py:215-226"""
-        ws = list(self.density.shape[2:])
-        xyz = self._grid_xyz(ws, self.density.device)
-        nearest = torch.stack([(xyz.unsqueeze(-2) - co).pow(2).sum(-1).sqrt().amin(-1)
-                               for co in cam_o.to(xyz.device).split(100)]).amin(0)
-        self.density[nearest[None, None] <= near] = -100
+        """lib/dvgo.py:215-226: density = -100 wherever a training camera is within `near` (one kernel over the voxels,
+        csrc/maintain.hip; the voxel centres are the reference's torch.linspace coordinates)."""
+        dev = self.density.device
+        X, Y, Z = (int(v) for v in self.density.shape[2:])
+        gx, gy, gz = (torch.linspace(float(self._xyz_min_cpu[a]), float(self._xyz_max_cpu[a]), n, device=dev)
+                      for a, n in enumerate((X, Y, Z)))
+        cams = torch.as_tensor(cam_o, dtype=torch.float32).reshape(-1, 3).to(dev).contiguous()
+        with L.device_of(self.density):
+            L.call('dvgo_maskout_near_cam', ptr(self.density), ptr(gx), ptr(gy), ptr(gz), _int(X), _int(Y), _int(Z),
+                   ptr(cams), _int(cams.shape[0]), _flt(float(near)), _flt(-100.0), stream_of(self.density))
 
     @torch.no_grad()
     def scale_volume_grid(self, num_voxels):
@@ -219,36 +223,29 @@ class DirectVoxGO(nn.Module):
                                     xyz_max=self._xyz_max_cpu).to(self.density.device)
         self._cfg_cache = {}
 
+    @torch.no_grad()
     def voxel_count_views(self, rays_o_tr, rays_d_tr, imsz, near, far, stepsize, downrate=1, irregular_shape=False):
-        """How many views see each voxel (lib/dvgo.py:265-295); drives the per-voxel lr."""
-        eps_time = time.time()
-        N_samples = int(np.linalg.norm(np.array(self.density.shape[2:]) + 1) / stepsize) + 1
+        """How many training views see each voxel (lib/dvgo.py:265-295; drives the coarse stage's per-voxel learning
+        rate, run.py:311-320).  The reference pushes ones through grid_sample and reads `ones.grad > 1` per view; here
+        the per-view weight sums are accumulated by one kernel (one wavefront per ray) and committed by another
+        (csrc/maintain.hip) -- same argument meaning, returns count [1,1,X,Y,Z] float."""
         dev = self.density.device
-        rng = torch.arange(N_samples, device=dev)[None].float()
+        X, Y, Z = (int(v) for v in self.density.shape[2:])
+        n_samples = int(np.linalg.norm(np.array([X, Y, Z]) + 1) / stepsize) + 1
+        step = float(np.float32(stepsize) * self.voxel_size.numpy().astype(np.float32))
         count = torch.zeros_like(self.density.detach())
-        xyz_min, xyz_max = self.xyz_min.to(dev), self.xyz_max.to(dev)
-        voxel_size = float(self.voxel_size)
-        for rays_o_, rays_d_ in zip(rays_o_tr.split(imsz), rays_d_tr.split(imsz)):
-            ones = torch.ones_like(self.density).requires_grad_()
-            if irregular_shape:
-                rays_o_ = rays_o_.split(10000)
-                rays_d_ = rays_d_.split(10000)
-            else:
-                rays_o_ = rays_o_[::downrate, ::downrate].to(dev).flatten(0, -2).split(10000)
-                rays_d_ = rays_d_[::downrate, ::downrate].to(dev).flatten(0, -2).split(10000)
-            for rays_o, rays_d in zip(rays_o_, rays_d_):
-                vec = torch.where(rays_d == 0, torch.full_like(rays_d, 1e-6), rays_d)
-                rate_a = (xyz_max - rays_o) / vec
-                rate_b = (xyz_min - rays_o) / vec
-                t_min = torch.minimum(rate_a, rate_b).amax(-1).clamp(min=near, max=far)
-                step = stepsize * voxel_size * rng
-                interpx = (t_min[..., None] + step / rays_d.norm(dim=-1, keepdim=True))
-                rays_pts = rays_o[..., None, :] + rays_d[..., None, :] * interpx[..., None]
-                self.grid_sampler(rays_pts, ones).sum().backward()
-            with torch.no_grad():
-                count += (ones.grad > 1)
-        if self.verbose:
-            print('dvgo_amd: voxel_count_views', time.time() - eps_time, 's')
+        acc = torch.zeros(X * Y * Z, dtype=torch.float32, device=dev)
+        mn, mx = f3(self._xyz_min_cpu), f3(self._xyz_max_cpu)
+        with L.device_of(self.density):
+            st = stream_of(self.density)
+            for rays_o_, rays_d_ in zip(rays_o_tr.split(imsz), rays_d_tr.split(imsz)):
+                if not irregular_shape:
+                    rays_o_, rays_d_ = rays_o_[::downrate, ::downrate], rays_d_[::downrate, ::downrate]
+                ro = rays_o_.to(dev).reshape(-1, 3).float().contiguous()
+                rd = rays_d_.to(dev).reshape(-1, 3).float().contiguous()
+                L.call('dvgo_view_weight_accumulate', ptr(ro), ptr(rd), _i64(ro.shape[0]), mn, mx, _flt(float(near)),
+                       _flt(float(far)), _flt(step), _int(n_samples), _int(X), _int(Y), _int(Z), ptr(acc), st)
+                L.call('dvgo_view_count_commit', ptr(acc), ptr(count), _i64(X * Y * Z), st)
         return count
 
     def density_total_variation_add_grad(self, weight, dense_mode):

@@ -61,23 +61,34 @@ def _rec_stride(cfg, n_rays):
     return stride
 
 
+# Owner-computes gradient scatter (csrc/brick.hip): samples are listed per 8x8x8 brick, one workgroup sums a brick;
+# no float atomics, no zero-fill.  The default whenever both grids want a gradient, share the lattice and the
+# feature grid is channels-last with a built channel count; the atomic scatters below remain as A/B variants.
+BRICK_SCATTER = True
+BRICK_CHANNELS = (3, 4, 9, 12)
+
 # A/B switch (tests, tools): scatter both grid gradients through one buffer of 64-byte voxel rows
 COMBINED_GRID_GRAD = True
 COMBINED_MIN_RATIO = 6          # use it when kept samples * ratio >= voxels (tests set 1e9 to force it)
 
 
 class grid_rows_capture:
-    """Context manager for a training step that owns the optimizer: inside it, a backward that scattered into combined
-    gradient rows hands them over (`.G`: [n_vox, 16] = 12 feature channels, the density gradient, pad) INSTEAD of
-    splitting them into `k0.grad` / `density.grad` -- those two stay `None` -- so that the optimizer can update both
-    grids straight from the rows (`MaskedAdam.step_grid_rows`).  Only for the (density, k0) parameters given."""
+    """Context manager for a training step that owns the optimizer: inside it the march backward does NOT produce
+    `k0.grad` / `density.grad` (those two stay `None`).  Either
+      * `adam` is given (a callable returning the argument tail of dvgo_brick_accumulate, see
+        `MaskedAdam.grid_step_args`) and the brick scatter applies the masked Adam update of both grids in place, from
+        the brick's gradient tile in LDS -- the gradient never exists in memory (`.stepped` is set); or
+      * the atomic scatter into combined gradient rows hands them over (`.G`: [n_vox, 16] = 12 feature channels, the
+        density gradient, pad) so that the optimizer can update both grids straight from the rows
+        (`MaskedAdam.step_grid_rows`).
+    Only for the (density, k0) parameters given."""
     _active = None
 
-    def __init__(self, density, k0):
-        self.density, self.k0, self.G = density, k0, None
+    def __init__(self, density, k0, adam=None):
+        self.density, self.k0, self.G, self.adam, self.stepped = density, k0, None, adam, False
 
     def __enter__(self):
-        self.G = None
+        self.G, self.stepped = None, False
         grid_rows_capture._active = self
         return self
 
@@ -139,15 +150,30 @@ class _FusedMarch(torch.autograd.Function):
                 cap = stride * N
             rec2 = torch.empty((max(cap, 1), 4), dtype=torch.float32, device=dev)
             rec3 = torch.empty((max(cap, 1), 4), dtype=torch.float32, device=dev)
+            # training: count, per 8^3 brick, the samples the backward will list for it (csrc/brick.hip)
+            bricks = (BRICK_SCATTER and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and C in BRICK_CHANNELS
+                      and tuple(density.shape[2:]) == (X, Y, Z) and (sC, sZ, sY, sX) == (1, C, Z * C, Y * Z * C)
+                      and k0.data_ptr() % 16 == 0 and N > 0)
+            brick_cnt = brick_off = brick_cur = None
+            if bricks:
+                nb = L.lib().dvgo_n_bricks(X, Y, Z)
+                brick_cnt = torch.zeros(nb, dtype=torch.int32, device=dev)
+                brick_off = torch.empty(nb + 1, dtype=torch.int32, device=dev)
+                brick_cur = torch.empty(nb, dtype=torch.int32, device=dev)
             mask = cfg.mask
             mshape = mask.shape if mask is not None else (0, 0, 0)
             L.call('dvgo_march_density', ptr(start), ptr(dirs), ptr(n_steps), ptr(cum), _i64(stride), _i64(N),
                    cfg.xyz_min_h, cfg.xyz_max_h, _flt(cfg.stepdist), ptr(mask), _int(mshape[0]), _int(mshape[1]),
                    _int(mshape[2]), cfg.scale_h, cfg.shift_h, ptr(density), _int(X), _int(Y), _int(Z),
                    _flt(cfg.act_shift), _flt(cfg.interval), _flt(cfg.thres), ptr(rec2), ptr(rec3), ptr(n2), ptr(n3),
-                   ptr(last), st)
+                   ptr(last), ptr(brick_cnt), st)
             L.call('dvgo_exclusive_scan_i32', ptr(n3), _i64(N), ptr(off3), st)
-            M3 = int(off3[-1].item())                          # the one host sync of the fused forward
+            n_entries = 0
+            if bricks:
+                L.call('dvgo_brick_scan', ptr(brick_cnt), _int(nb), ptr(brick_off), ptr(brick_cur), st)
+                M3, n_entries = torch.stack((off3[-1], brick_off[-1].long())).tolist()   # the one host sync
+            else:
+                M3 = int(off3[-1].item())                      # the one host sync of the fused forward
             ray_id = torch.empty(M3, dtype=torch.int64, device=dev)
             step_id = torch.empty(M3, dtype=torch.int64, device=dev)
             weights = torch.empty(M3, dtype=torch.float32, device=dev)
@@ -160,6 +186,7 @@ class _FusedMarch(torch.autograd.Function):
         del rec3
         ctx.cfg = cfg
         ctx.geom = (X, Y, Z, C, sC, sX, sY, sZ, stride, N)
+        ctx.bricks = (brick_off, brick_cur, n_entries) if bricks else None
         ctx.density_meta, ctx.k0_meta = density, k0
         ctx.save_for_backward(rec2, n2, n_steps, cum if cum is not None else n_steps, off3, start, dirs, last,
                               ray_id, step_id)
@@ -186,11 +213,37 @@ class _FusedMarch(torch.autograd.Function):
                 gw = g_w.contiguous() if g_w is not None else torch.zeros(M3, dtype=torch.float32, device=dev)
                 gl = g_last.contiguous() if g_last is not None else None
 
-            def density_bwd(dst, dst_stride, kept):
+            def density_bwd(dst, dst_stride, kept, cursor=None, recs=None):
                 L.call('dvgo_march_density_bwd', ptr(rec2), ptr(n2), ptr(n_steps), cum_p, _i64(stride), ptr(off3),
                        _i64(N), ptr(start), ptr(dirs), _flt(cfg.stepdist), cfg.xyz_min_h, cfg.xyz_max_h, ptr(last),
                        _flt(cfg.interval), ptr(gw), ptr(gl), _int(X), _int(Y), _int(Z), ptr(dst), _i64(dst_stride),
-                       ptr(kept), st)
+                       ptr(kept), ptr(cursor), ptr(recs), st)
+
+            if ctx.bricks is not None and want_k0 and want_d and BRICK_SCATTER:
+                # owner-computes scatter: list every sample per brick, then one workgroup sums each brick
+                brick_off, brick_cur, E = ctx.bricks
+                ctx.bricks = None                               # the fill cursors are consumed: one backward per forward
+                recs = torch.empty((max(E, 1), 4), dtype=torch.int32, device=dev)
+                density_bwd(None, 1, None, brick_cur, recs)
+                g_feat = g_feat.contiguous()
+                cap = grid_rows_capture._active
+                fuse = (cap is not None and cap.adam is not None and not cap.stepped and cap.density is ctx.density_meta
+                        and cap.k0 is ctx.k0_meta)
+                if fuse:
+                    tail = cap.adam()
+                    L.call('dvgo_brick_accumulate', ptr(brick_off), ptr(recs), ptr(start), ptr(dirs), _flt(cfg.stepdist),
+                           cfg.xyz_min_h, cfg.xyz_max_h, ptr(g_feat), _int(C), _int(X), _int(Y), _int(Z), ptr(None), ptr(None),
+                           *tail, st)
+                    cap.stepped = True
+                    return None, None, None, None, None
+                grad_k0 = torch.empty_like(ctx.k0_meta, memory_format=torch.preserve_format)
+                grad_density = torch.empty_like(ctx.density_meta)
+                assert grad_k0.stride() == ctx.k0_meta.stride() and grad_density.is_contiguous()
+                L.call('dvgo_brick_accumulate', ptr(brick_off), ptr(recs), ptr(start), ptr(dirs), _flt(cfg.stepdist),
+                       cfg.xyz_min_h, cfg.xyz_max_h, ptr(g_feat), _int(C), _int(X), _int(Y), _int(Z), ptr(grad_k0),
+                       ptr(grad_density), ptr(None), ptr(None), ptr(None), _flt(0), _int(0),
+                       ptr(None), ptr(None), ptr(None), _flt(0), _int(0), _flt(0), _flt(0), _flt(0), st)
+                return grad_density, grad_k0, None, None, None
 
             # worth its two extra full-grid passes (zero 64 B, split 116 B per voxel) from ~1 kept sample per 6 voxels
             combined = (COMBINED_GRID_GRAD and want_k0 and want_d and C == 12 and M3 * COMBINED_MIN_RATIO >= X * Y * Z and tuple(ctx.density_meta.shape[2:]) == (X, Y, Z)

@@ -81,6 +81,12 @@ class MaskedAdam(torch.optim.Optimizer):
             st.update(step=0,
                       exp_avg=torch.zeros_like(p, memory_format=torch.preserve_format),
                       exp_avg_sq=torch.zeros_like(p, memory_format=torch.preserve_format))
+        else:
+            # state restored from a checkpoint arrives in the canonical contiguous layout (checkpoint.py, and any
+            # reference-written file): the update kernels are element-wise over raw memory, so re-lay it once
+            for k in ('exp_avg', 'exp_avg_sq'):
+                if st[k].stride() != p.stride() or st[k].device != p.device:
+                    st[k] = self._like(p, st[k].to(p.device))
         return st
 
     @staticmethod
@@ -103,8 +109,44 @@ class MaskedAdam(torch.optim.Optimizer):
             return False
         if self.per_lr is not None and self.per_lr.shape in (density.shape, k0.shape):
             return False                                  # per-voxel learning rates go through the dense kernels
+        for p in (density, k0):                     # the rows kernel walks raw memory: a resumed (contiguous) state
+            if self.state.get(p):                   # is re-laid to the parameter's strides first
+                self._state_of(p)
         return (k0.dim() == 5 and k0.shape[1] == 12 and k0.is_contiguous(memory_format=torch.channels_last_3d)
                 and density.is_contiguous() and density.shape[2:] == k0.shape[2:])
+
+    def can_fuse_grid_step(self, density, k0):
+        """True when the brick scatter may apply this optimizer's update of the two grids itself
+        (`grid_step_args`): as `can_step_grid_rows` (any built channel count), and both groups must be masked
+        (`skip_zero_grad`) -- the fused update only visits the bricks a sample touched, which is the set the masked
+        rule (adam_upd_kernel.cu:35) updates; plain Adam also moves voxels whose gradient is zero."""
+        gd, gk = self._group_of(density), self._group_of(k0)
+        if gd is None or gk is None or gd['betas'] != gk['betas'] or gd['eps'] != gk['eps']:
+            return False
+        if not (gd.get('skip_zero_grad', False) and gk.get('skip_zero_grad', False)):
+            return False
+        if self.per_lr is not None and self.per_lr.shape in (density.shape, k0.shape):
+            return False
+        if not (k0.dim() == 5 and k0.shape[1] > 1 and k0.is_contiguous(memory_format=torch.channels_last_3d)
+                and density.is_contiguous() and density.shape[2:] == k0.shape[2:]):
+            return False
+        for p in (density, k0):                     # a resumed state arrives contiguous: re-lay it to the parameter's
+            if self.state.get(p):                   # strides first (the kernels walk raw memory)
+                self._state_of(p)
+        return True
+
+    def grid_step_args(self, density, k0):
+        """Counts one step for both grids and returns the Adam argument tail of dvgo_brick_accumulate
+        (csrc/brick.hip): the update `step()` would make, applied by the scatter kernel from its LDS tile."""
+        gd, gk = self._group_of(density), self._group_of(k0)
+        sd, sk = self._state_of(density), self._state_of(k0)
+        sd['step'] += 1
+        sk['step'] += 1
+        b1, b2 = gk['betas']
+        return (ptr(k0), ptr(sk['exp_avg']), ptr(sk['exp_avg_sq']), _flt(adam_step_size(gk['lr'], b1, b2, sk['step'])),
+                _int(1 if gk.get('skip_zero_grad', False) else 0),
+                ptr(density), ptr(sd['exp_avg']), ptr(sd['exp_avg_sq']), _flt(adam_step_size(gd['lr'], b1, b2, sd['step'])),
+                _int(1 if gd.get('skip_zero_grad', False) else 0), _flt(b1), _flt(b2), _flt(gk['eps']))
 
     @torch.no_grad()
     def step_grid_rows(self, density, k0, G):

@@ -171,12 +171,13 @@ class MaskCache(nn.Module):
     def __init__(self, path=None, mask_cache_thres=None, mask=None, xyz_min=None, xyz_max=None):
         super().__init__()
         if path is not None:
-            st = torch.load(path, map_location='cpu', weights_only=False)   # our own / user checkpoints
+            from .checkpoint import safe_load
+            st = safe_load(path)                    # weights-only: nothing in the file is executed
             self.mask_cache_thres = mask_cache_thres
             density = F.max_pool3d(st['model_state_dict']['density'].float().contiguous(), kernel_size=3,
                                    padding=1, stride=1)
             kw = st['model_kwargs']
-            alpha = 1 - torch.exp(-F.softplus(density + kw['act_shift']) * kw['voxel_size_ratio'])
+            alpha = 1 - torch.exp(-F.softplus(density + float(kw['act_shift'])) * float(kw['voxel_size_ratio']))
             mask = (alpha >= self.mask_cache_thres).squeeze(0).squeeze(0)
             xyz_min = torch.as_tensor(kw['xyz_min'], dtype=torch.float32)
             xyz_max = torch.as_tensor(kw['xyz_max'], dtype=torch.float32)

@@ -128,8 +128,12 @@ class TrainStep:
     """One optimisation step on one batch of rays; ``world_size > 1`` shards the batch by rank."""
 
     def __init__(self, model, cfg_train, render_kwargs, optimizer=None, process_group=None, fused_loss=True,
-                 overlap_wgrad=True, touched_reduce=True, rows_adam=True):
+                 overlap_wgrad=True, touched_reduce=True, rows_adam=True, track_mse=False):
         self.model = model
+        # weight_main * mse of the step, the quantity run.py:378 turns into the logged PSNR (before the entropy and
+        # per-point terms are added); kept on the device, no sync
+        self.track_mse = track_mse
+        self.last_mse = None
         # one GPU, no TV this step: Adam reads the combined gradient rows of the fused backward directly
         # (fused.grid_rows_capture / MaskedAdam.step_grid_rows); density.grad / k0.grad then stay None
         self.rows_adam = rows_adam
@@ -238,6 +242,8 @@ class TrainStep:
         self.optimizer.zero_grad(set_to_none=True)
         loss_fn = fused_render_loss if (self.fused_loss and res['rgb_marched'].is_cuda) else render_loss
         loss = loss_fn(res, target, n_global, cfg)
+        if self.track_mse:
+            self.last_mse = cfg['weight_main'] * (res['rgb_marched'].detach() - target).pow(2).sum() / (3 * n_global)
         # backward order: ... colour-head data gradient -> grid scatters.  One GPU: the colour head's weight-gradient
         # kernel runs on a second stream beside the scatters.  Data parallel: it is postponed until the grid
         # all-reduce has been STARTED -- its persistent workgroups fill every CU, and RCCL's kernels, arriving
@@ -245,17 +251,22 @@ class TrainStep:
         tv_now = (cfg['tv_after'] < global_step < cfg['tv_before'] and global_step % cfg['tv_every'] == 0 and
                   (cfg['weight_tv_density'] > 0 or cfg['weight_tv_k0'] > 0))
         density, k0 = getattr(model, 'density', None), getattr(model, 'k0', None)
-        use_rows = (self.rows_adam and self.world == 1 and not tv_now and isinstance(self.optimizer, MaskedAdam)
-                    and isinstance(density, nn.Parameter) and isinstance(k0, nn.Parameter) and density.is_cuda
-                    and self.optimizer.can_step_grid_rows(density, k0))
-        rows = grid_rows_capture(density, k0) if use_rows else contextlib.nullcontext()
+        own = (self.rows_adam and self.world == 1 and not tv_now and isinstance(self.optimizer, MaskedAdam)
+               and isinstance(density, nn.Parameter) and isinstance(k0, nn.Parameter) and density.is_cuda)
+        fuse_adam = own and self.optimizer.can_fuse_grid_step(density, k0)
+        use_rows = fuse_adam or (own and self.optimizer.can_step_grid_rows(density, k0))
+        opt = self.optimizer
+        rows = (grid_rows_capture(density, k0, adam=(lambda: opt.grid_step_args(density, k0)) if fuse_adam else None)
+                if use_rows else contextlib.nullcontext())
         with defer_wgrad(side_stream=self.overlap_wgrad and self.world == 1) as deferred, rows as cap:
             _FusedLoss.unit_grad = True
             try:
                 loss.backward()
             finally:
                 _FusedLoss.unit_grad = False
-        if use_rows and cap.G is not None:
+        if use_rows and cap.stepped:
+            assert density.grad is None and k0.grad is None    # both grids were updated inside the backward (csrc/brick.hip)
+        elif use_rows and cap.G is not None:
             if density.grad is None and k0.grad is None:
                 self.optimizer.step_grid_rows(density, k0, cap.G)  # (.grad of the two grids is None: step() below skips them)
             else:                                                 # more than one march in the graph: fold the rows back

@@ -199,7 +199,11 @@ int dvgo_march_density(const float* rays_start, const float* rays_dir,
                        const float* density, int X, int Y, int Z,            /* [X,Y,Z] contiguous */
                        float act_shift, float interval, float fast_color_thres,
                        dvgo_rec2_t* rec2, dvgo_rec3_t* rec3,
-                       int32_t* n2, int32_t* n3, float* alphainv_last, void* stream);
+                       int32_t* n2, int32_t* n3, float* alphainv_last,
+                       int32_t* brick_cnt /* NULL, or [dvgo_n_bricks(X,Y,Z)] zero-initialised counters: the samples
+                                             that entered compositing are counted per brick for the backward's
+                                             owner-computes scatter (see "Brick scatter" below) */,
+                       void* stream);
 
 /* dvgo_march_hit: hit[r] = 1 iff ray r has an in-box sample whose nearest occupancy voxel is set -- the fused
  *   form of DirectVoxGO.hit_coarse_geo (lib/dvgo.py:412-423), one wavefront per ray.  Host pointers as above. */
@@ -258,7 +262,11 @@ int dvgo_march_feat_bwd(const float* grad_feat, const float* grad_extra, const i
  *   grad_density[v * grad_stride]; 1 for the plain [X,Y,Z] grid).
  *   grad_weights is indexed in the M3 order of dvgo_march_gather; grad_last may be NULL (= 0).
  *   grad_kept (NULL or [M3]): when given, the samples kept by dvgo_march_gather write their density gradient there
- *   (for dvgo_march_feat_bwd's grad_extra) instead of scattering it; only the dropped ones are scattered here. */
+ *   (for dvgo_march_feat_bwd's grad_extra) instead of scattering it; only the dropped ones are scattered here.
+ *   brick_cursor (NULL or [n_bricks], from dvgo_brick_scan): when given nothing is scattered here (grad_density and
+ *   grad_kept are ignored): every sample is appended to the list of each brick it touches -- brick_recs[slot] =
+ *   {int32 kept index in the M3 order or -1, int32 ray, int32 step, float density gradient} (16 B) -- for
+ *   dvgo_brick_accumulate. */
 int dvgo_march_density_bwd(const dvgo_rec2_t* rec2, const int32_t* n2, const int64_t* n_steps,
                            const int64_t* n_steps_cumsum, int64_t rec_stride, const int64_t* off3,
                            int64_t n_rays,
@@ -267,12 +275,59 @@ int dvgo_march_density_bwd(const dvgo_rec2_t* rec2, const int32_t* n2, const int
                            const float* alphainv_last, float interval,
                            const float* grad_weights /* [M3] */, const float* grad_last /* [N] */,
                            int X, int Y, int Z, float* grad_density, int64_t grad_stride, float* grad_kept,
+                           int32_t* brick_cursor, void* brick_recs,
                            void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * Brick scatter: the grid-gradient sums of grid_sampler_3d_backward (behind lib/dvgo.py:321; 8*C float atomics per
+ * sample in the reference) without atomics.  The lattice is cut into 8x8x8-voxel bricks; a workgroup owns one brick,
+ * sums the contributions of the samples listed for it and either writes the dense gradients with plain stores
+ * (every voxel of the grid is written: zeros where no sample came by) or applies the Adam update in place.
+ *   dvgo_n_bricks        number of bricks of an [X,Y,Z] lattice
+ *   dvgo_brick_scan      counts [n] -> offsets [n+1] (offsets[n] = number of list entries E) and fill cursors [n]
+ *   dvgo_brick_accumulate
+ *     brick_off [n+1]; recs [E] 16-byte records as written by dvgo_march_density_bwd; rays_start / rays_dir /
+ *     stepdist / xyz_min / xyz_max (host) as given to dvgo_march_density (sample positions are rebuilt from the
+ *     records' ray and step); grad_feat [M3,C] (the gradient w.r.t. the gathered features); density and k0 share the
+ *     lattice, k0 channels-last.
+ *     p_k0 == NULL : writes grad_k0 [X,Y,Z,C] (channels-last) and grad_density [X,Y,Z], all of both.
+ *     p_k0 != NULL : MaskedAdam in place on (p, exp_avg, exp_avg_sq) of k0 and density
+ *                    (adam_upd_cuda.adam_upd / masked_adam_upd, lib/cuda/adam_upd.cpp:36-68; step sizes bias-corrected
+ *                    on the host as adam_upd_kernel.cu:72; masked_* = skip elements whose gradient is exactly 0);
+ *                    voxels of bricks no sample touched are left alone either way (their gradient is zero: the masked
+ *                    update skips them; for an unmasked group use the dense path).
+ *     Built for C in {3, 4, 9, 12}; DVGO_ERANGE otherwise.
+ * --------------------------------------------------------------------------------- */
+int dvgo_n_bricks(int X, int Y, int Z);
+int dvgo_brick_scan(const int32_t* brick_cnt, int n_bricks, int32_t* brick_off, int32_t* brick_cursor, void* stream);
+int dvgo_brick_accumulate(const int32_t* brick_off, const void* recs, const float* rays_start, const float* rays_dir,
+                          float stepdist, const float* xyz_min, const float* xyz_max, const float* grad_feat,
+                          int C, int X, int Y, int Z, float* grad_k0, float* grad_density,
+                          float* p_k0, float* m_k0, float* v_k0, float step_size_k0, int masked_k0,
+                          float* p_density, float* m_density, float* v_density, float step_size_density,
+                          int masked_density, float beta1, float beta2, float eps, void* stream);
 
 /* Combined gradient rows G [n_vox][row_stride] (built by the two calls above) -> the channels-last feature
  * gradient [n_vox][C] and the density gradient [n_vox], both fully written.  Built for row_stride 16, C 12. */
 int dvgo_grid_grad_split(const float* G, int64_t n_vox, int row_stride, int C, float* grad_k0, float* grad_density,
                          void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * "next" row N4: coarse-stage grid maintenance.
+ *   voxel_count_views (lib/dvgo.py:265-295): per training view, acc[v] = sum of the trilinear weights voxel v receives
+ *   from the view's sample points (o + d * (t_min + k * step / |d|), k < n_samples, t_min = slab entry clamped to
+ *   [near, far]); count[v] += (acc[v] > 1).  Call dvgo_view_weight_accumulate for the rays of ONE view (any number of
+ *   calls), then dvgo_view_count_commit, which also clears acc for the next view.  acc, count: [X*Y*Z] floats, acc zero
+ *   on first use.  xyz_min / xyz_max are HOST pointers.
+ *   maskout_near_cam_vox (lib/dvgo.py:215-226): density[v] = value where min_c |xyz(v) - cam_o[c]| <= near;
+ *   grid_x/y/z are the per-axis voxel-centre coordinates (device, [X] / [Y] / [Z]), cam_o [n_cam,3].
+ * --------------------------------------------------------------------------------- */
+int dvgo_view_weight_accumulate(const float* rays_o, const float* rays_d, int64_t n_rays, const float* xyz_min,
+                                const float* xyz_max, float near, float far, float step, int n_samples, int X, int Y,
+                                int Z, float* acc, void* stream);
+int dvgo_view_count_commit(float* acc, float* count, int64_t n_vox, void* stream);
+int dvgo_maskout_near_cam(float* density, const float* grid_x, const float* grid_y, const float* grid_z, int X, int Y, int Z,
+                          const float* cam_o, int n_cam, float near, float value, void* stream);
 
 /* ---------------------------------------------------------------------------------
  * "next" row N3: fused colour head (rgbnet) forward.  Replaces lib/dvgo.py:516-541 for the

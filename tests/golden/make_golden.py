@@ -337,6 +337,46 @@ def gen_voxel_count_views(R):
          count=cnt)
 
 
+def gen_checkpoint(R):
+    """N5: a checkpoint written exactly as run.py:430-437 writes it -- torch.save of {'global_step', 'model_kwargs':
+    model.get_kwargs() (numpy bbox, numpy act_shift, tensor voxel_size_ratio, the fork's extra flags),
+    'model_state_dict', 'optimizer_state_dict'} -- from the imported reference DirectVoxGO and MaskedAdam (param groups
+    as lib/utils.py:20-48 builds them) after one optimisation step, so that the Adam moments exist, in the
+    reference's contiguous [1,C,X,Y,Z] layout.  `ref_checkpoint_next.npz` holds the batch and the reference's
+    parameters after ONE MORE step from that state: what a resumed run must reproduce."""
+    rng = np.random.default_rng(911)
+    m, mn, mx = _scene(R, rng, fine=True, nvox=10 ** 3, width=32)
+    ro, rd, vd = lego_like_rays(R, rng, n_views=4, H=6, W=6, focal=6 * 1111.11 / 800 * 3.0, radius=3.0)
+    target = torch.from_numpy(rng.random((ro.shape[0], 3)).astype(np.float32))
+    rk = dict(near=0.5, far=6.0, bg=1, stepsize=0.5, inverse_y=False, flip_x=False, flip_y=False)
+    groups = [{'params': m.density, 'lr': 0.1, 'skip_zero_grad': True},
+              {'params': m.k0, 'lr': 0.1, 'skip_zero_grad': True},
+              {'params': m.rgbnet.parameters(), 'lr': 1e-3, 'skip_zero_grad': False}]
+    opt = R.masked_adam.MaskedAdam(groups)
+    decay = 0.1 ** (1 / 20000)
+
+    def one_step(step):
+        res = m(ro, rd, vd, global_step=step, **rk)
+        opt.zero_grad(set_to_none=True)
+        _loss(res, target, ro.shape[0]).backward()
+        opt.step()
+        for g in opt.param_groups:
+            g['lr'] = g['lr'] * decay
+
+    one_step(1)
+    path = os.path.join(HERE, 'ref_checkpoint.tar')
+    torch.save({'global_step': 1, 'model_kwargs': m.get_kwargs(), 'model_state_dict': m.state_dict(),
+                'optimizer_state_dict': opt.state_dict()}, path)
+    print('wrote', path, os.path.getsize(path) // 1024, 'KiB')
+    one_step(2)
+    out = {'rays_o': ro, 'rays_d': rd, 'viewdirs': vd, 'target': target, 'density': m.density, 'k0': m.k0}
+    for k, p in m.rgbnet.named_parameters():
+        out['rgbnet_' + k] = p
+    st = opt.state[m.k0]
+    out['k0_exp_avg'] = st['exp_avg']; out['k0_step'] = st['step']
+    save('ref_checkpoint_next', **{k: v for k, v in out.items()}, **{kk: np.asarray(vv) for kk, vv in rk.items() if kk in ('near', 'far', 'stepsize')})
+
+
 def gen_masked_adam(R):
     """N1 host logic: reference MaskedAdam.step (lib/masked_adam.py:39-71) for the three dispatch
     branches, 3 steps each; natives = oracle."""
@@ -414,6 +454,9 @@ def main():
         if len(sys.argv) > 1 and sys.argv[1] == 'forward_fine_direct':      # add this one fixture only
             gen_forward(R, fine=True, name='forward_fine_direct', width=128, direct=True)
             return
+        if len(sys.argv) > 1 and sys.argv[1] == 'checkpoint':
+            gen_checkpoint(R)
+            return
         if len(sys.argv) > 1 and sys.argv[1] == 'forward_mpi_w64':
             gen_mpi_forward(R, width=64, name='forward_mpi_w64')
             return
@@ -428,6 +471,7 @@ def main():
         gen_mpi_forward(R, width=64, name='forward_mpi_w64')
         gen_voxel_count_views(R)
         gen_masked_adam(R)
+        gen_checkpoint(R)
         gen_trajectory(R)
         gen_rays(R)
     finally:

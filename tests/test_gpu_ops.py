@@ -439,4 +439,6 @@ def test_deferred_wgrad_gives_identical_parameter_gradients():
     d.flush()
     assert torch.equal(feat.grad, gf)
     for p, r in zip(net.parameters(), ref):
-        assert torch.allclose(p.grad, r, rtol=1e-5, atol=1e-6)
+        # the per-workgroup partial sums are combined with float atomics: two runs differ by summation order, i.e. by
+        # rounding relative to the LARGEST terms of a sum, not to a result that may have cancelled to near zero
+        assert float((p.grad - r).abs().max()) <= 1e-5 * float(r.abs().max())

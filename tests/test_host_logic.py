@@ -160,7 +160,8 @@ def test_checkpoint_round_trip_in_reference_format(tmp_path):
         m.density.normal_(); m.k0.normal_()
     p = str(tmp_path / 'fine_last.tar')
     save_checkpoint(p, m, None, 123)
-    ck = torch.load(p, weights_only=False)
+    from directvoxgo_amd.checkpoint import safe_load
+    ck = safe_load(p)
     assert set(ck) == {'global_step', 'model_kwargs', 'model_state_dict', 'optimizer_state_dict'}
     assert ck['model_state_dict']['k0'].is_contiguous() and ck['global_step'] == 123
     m2 = load_model(DirectVoxGO, p)
@@ -169,3 +170,77 @@ def test_checkpoint_round_trip_in_reference_format(tmp_path):
         assert torch.equal(a, b), k
     mc = MaskCache(path=p, mask_cache_thres=1e-3)
     assert mc.mask.shape == (9, 9, 9)
+
+
+def test_reference_written_checkpoint_loads_without_executing_anything():
+    """tests/golden/ref_checkpoint.tar was written by the imported reference (tests/golden/make_golden.py
+    gen_checkpoint: run.py:430-437 dict, DirectVoxGO.get_kwargs() with numpy values, contiguous grids and Adam moments).
+    It must load through the weights-only loader (only numpy's array / scalar reconstructors allow-listed), rebuild the
+    model (lib/utils.py:63-79) and feed MaskCache(path=...) (lib/dvgo.py:586-593)."""
+    import os
+    from conftest import GOLDEN
+    from directvoxgo_amd.checkpoint import load_model, model_kwargs_of, safe_load
+    from directvoxgo_amd.dvgo import DirectVoxGO
+    from directvoxgo_amd.ops import MaskCache
+    path = os.path.join(GOLDEN, 'ref_checkpoint.tar')
+    ck = safe_load(path)
+    assert set(ck) == {'global_step', 'model_kwargs', 'model_state_dict', 'optimizer_state_dict'}
+    kw = ck['model_kwargs']
+    assert isinstance(kw['xyz_min'], np.ndarray) and isinstance(kw['act_shift'], np.floating)      # as the reference writes them
+    sd = ck['model_state_dict']
+    assert sd['k0'].is_contiguous() and sd['k0'].shape[1] == 12 and sd['density'].dim() == 5
+    ost = ck['optimizer_state_dict']
+    assert ost['state'][1]['exp_avg'].is_contiguous() and ost['state'][1]['exp_avg'].shape == sd['k0'].shape
+    assert [g['skip_zero_grad'] for g in ost['param_groups']] == [True, True, False]
+    m = load_model(DirectVoxGO, path)
+    assert m.k0.stride()[1] == 1 and torch.equal(m.k0.detach().contiguous(), sd['k0'])            # channels-last in memory
+    assert set(m.state_dict()) == set(sd), set(m.state_dict()) ^ set(sd)
+    np.testing.assert_allclose(m.act_shift, float(kw['act_shift']), rtol=1e-12)
+    np.testing.assert_allclose(float(m.voxel_size_ratio), float(kw['voxel_size_ratio']), rtol=1e-6)
+    assert 'act_shift' not in model_kwargs_of(ck)
+    mc = MaskCache(path=path, mask_cache_thres=1e-3)
+    assert tuple(mc.mask.shape) == tuple(sd['density'].shape[2:]) and 0 < float(mc.mask.float().mean()) < 1
+
+
+def test_safe_load_refuses_a_pickle_that_would_run_code(tmp_path):
+    import os
+    import pickle
+    from directvoxgo_amd.checkpoint import safe_load
+    from directvoxgo_amd.ops import MaskCache
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ('echo pwned > ' + str(tmp_path / 'pwned'),))
+
+    p = str(tmp_path / 'evil.tar')
+    torch.save({'global_step': 1, 'model_kwargs': Evil(), 'model_state_dict': {}, 'optimizer_state_dict': None}, p)
+    with pytest.raises(pickle.UnpicklingError):
+        safe_load(p)
+    with pytest.raises(pickle.UnpicklingError):
+        MaskCache(path=p, mask_cache_thres=1e-3)
+    assert not (tmp_path / 'pwned').exists()
+
+
+def test_optimizer_state_is_saved_in_the_reference_layout_and_relaid_on_resume(tmp_path):
+    """the Adam moments of the channels-last feature grid are written contiguous [1,C,X,Y,Z] (what the
+    reference's adam_upd reads as raw memory) and come back in the parameter's strides."""
+    from directvoxgo_amd.checkpoint import load_checkpoint, safe_load, save_checkpoint
+    from directvoxgo_amd.dvgo import DirectVoxGO
+    from directvoxgo_amd.masked_adam import MaskedAdam
+    torch.manual_seed(0)
+    m = DirectVoxGO([-1, -1, -1], [1, 1, 1], num_voxels=7 ** 3, num_voxels_base=7 ** 3, alpha_init=1e-2, rgbnet_dim=12, rgbnet_width=16)
+    opt = MaskedAdam([{'params': [m.density], 'lr': 0.1, 'skip_zero_grad': True}, {'params': [m.k0], 'lr': 0.1, 'skip_zero_grad': True}])
+    st = opt._state_of(m.k0)
+    st['step'] = 4
+    st['exp_avg'].copy_(torch.randn(m.k0.shape)); st['exp_avg_sq'].copy_(torch.rand(m.k0.shape))
+    assert st['exp_avg'].stride() == m.k0.stride() and not st['exp_avg'].is_contiguous()
+    opt._state_of(m.density)
+    p = str(tmp_path / 'x.tar')
+    save_checkpoint(p, m, opt, 4)
+    on_disk = safe_load(p)['optimizer_state_dict']['state'][1]
+    assert on_disk['exp_avg'].is_contiguous() and torch.equal(on_disk['exp_avg'], st['exp_avg'].contiguous())
+    m2 = DirectVoxGO([-1, -1, -1], [1, 1, 1], num_voxels=7 ** 3, num_voxels_base=7 ** 3, alpha_init=1e-2, rgbnet_dim=12, rgbnet_width=16)
+    opt2 = MaskedAdam([{'params': [m2.density], 'lr': 0.1, 'skip_zero_grad': True}, {'params': [m2.k0], 'lr': 0.1, 'skip_zero_grad': True}])
+    load_checkpoint(m2, opt2, p)
+    st2 = opt2._state_of(m2.k0)
+    assert st2['step'] == 4 and st2['exp_avg'].stride() == m2.k0.stride() and torch.equal(st2['exp_avg'], st['exp_avg'])

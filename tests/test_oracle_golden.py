@@ -317,3 +317,34 @@ def test_total_variation_matches_autograd_of_huber_like_loss(oracle):
     g2 = np.zeros_like(p); g2[0, 0, 2, 3, 4] = 1.0
     oracle.total_variation_add_grad(p, g2, wx, wy, wz, False)
     assert np.count_nonzero(g2) == 1
+
+
+def test_pure_pytorch_restatement_matches_the_c_oracle(oracle):
+    """oracle/torch_cpu.py (the CPU baseline bench.py times on all host cores) against the scalar C oracle on a scene
+    without early ray termination (the cumulative-product form of the reference's docstring, lib/dvgo.py:651-656, has
+    no early stop): same kept samples, weights and pixel colours."""
+    import torch
+    from directvoxgo_amd.scenes import roofline_scene
+    from oracle import torch_cpu as TC
+    sc = roofline_scene(world=24, n_rays=64, n_samples=48, seed=3, device='cpu', k0_dim=3)
+    mn, mx = sc['xyz_min'].numpy(), sc['xyz_max'].numpy()
+    vs = np.float32(((sc['xyz_max'] - sc['xyz_min']).prod() / 24 ** 3) ** (1 / 3))
+    stepdist = np.float32(0.5) * vs
+    act_shift, interval, thres = float(np.log(1 / (1 - 1e-2) - 1)), 0.5, 1e-4
+    res = TC.render(sc['density'], sc['k0'], None, None, sc['rays_o'], sc['rays_d'], sc['viewdirs'], sc['xyz_min'],
+                    sc['xyz_max'], sc['near'], sc['far'], float(stepdist), 48, act_shift, interval, thres, 1.0)
+    pts, mo, rid, sid, *_ = oracle.sample_pts_on_rays(sc['rays_o'].numpy(), sc['rays_d'].numpy(), mn, mx, sc['near'],
+                                                      sc['far'], stepdist)
+    pts, rid = pts[~mo], rid[~mo]
+    dens = oracle.grid_sample_fwd(sc['density'][0].numpy(), pts, mn, mx)[:, 0]
+    _, alpha = oracle.raw2alpha(dens, act_shift, interval)
+    k = alpha > thres
+    pts, rid, alpha = pts[k], rid[k], alpha[k]
+    w, T, last, i_s, i_e = oracle.alpha2weight(alpha, rid, 64)
+    k = w > thres
+    assert np.array_equal(res['ray_id'].numpy(), rid[k])
+    np.testing.assert_allclose(res['weights'].numpy(), w[k], rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(res['alphainv_last'].numpy(), last, rtol=1e-4)
+    rgb = 1 / (1 + np.exp(-oracle.grid_sample_fwd(sc['k0'][0].numpy(), pts[k], mn, mx)))
+    marched = oracle.segment_sum((w[k][:, None] * rgb).astype(np.float32), rid[k], 64) + last[:, None]
+    np.testing.assert_allclose(res['rgb_marched'].numpy(), marched, atol=1e-5)
