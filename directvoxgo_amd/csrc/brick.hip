@@ -70,7 +70,7 @@ __device__ __forceinline__ void adam4(float4& p, const float4 g, float4& m, floa
 
 // ADAM: 0 = write the dense gradients, 1 = apply the (masked) Adam update in place
 template <int C, int ADAM>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 4)          // 4 workgroups per CU (LDS allows exactly 4): at most 128 VGPRs
 brick_accumulate_kernel(const int32_t* __restrict__ off, const int4* __restrict__ recs,
                         const float* __restrict__ rays_start, const float* __restrict__ rays_dir,
                         const float* __restrict__ g_feat, BrickGeom G, float* __restrict__ grad_k0,
@@ -106,36 +106,78 @@ brick_accumulate_kernel(const int32_t* __restrict__ off, const int4* __restrict_
 #pragma unroll
   for (int c = 0; c < CE; ++c) { acc0[c] = 0.f; acc1[c] = 0.f; }
 
+  // One list entry = {kept index or -1, ray, step, density gradient}; its payload (the sample's feature-gradient row
+  // and its ray) sits behind those indices: two dependent round trips to memory per chunk.  The loop therefore runs one
+  // chunk ahead: the records of chunk k+1 are requested before chunk k is processed and its payload right after the
+  // first barrier of chunk k, so both arrive under the sort and the accumulation.  The barriers below are bare
+  // `s_waitcnt lgkmcnt(0); s_barrier` -- __syncthreads() would also drain the vector-memory queue (vmcnt(0)) and stall
+  // on exactly those prefetches.
+  struct Payload {
+    float g[C];
+    float sx, sy, sz, dx, dy, dz;
+    float gd;
+    int step;
+  };
+  auto fetch = [&](const int4 rec, bool have) {
+    Payload P;
+#pragma unroll
+    for (int c = 0; c < C; ++c) P.g[c] = 0.f;
+    P.sx = P.sy = P.sz = P.dx = P.dy = P.dz = 0.f;
+    P.gd = __int_as_float(rec.w);
+    P.step = rec.z;
+    if (have) {
+      if (rec.x >= 0) {                            // (else: passed the alpha filter only, no feature gradient)
+        const float* src = g_feat + (int64_t)rec.x * C;
+        if constexpr (C % 4 == 0) {
+#pragma unroll
+          for (int c = 0; c < C / 4; ++c) {
+            const float4 v = reinterpret_cast<const float4*>(src)[c];
+            P.g[4 * c] = v.x; P.g[4 * c + 1] = v.y; P.g[4 * c + 2] = v.z; P.g[4 * c + 3] = v.w;
+          }
+        } else {
+#pragma unroll
+          for (int c = 0; c < C; ++c) P.g[c] = src[c];
+        }
+      }
+      const float* so = rays_start + 3 * (int64_t)rec.y;
+      const float* sd = rays_dir + 3 * (int64_t)rec.y;
+      P.sx = so[0]; P.sy = so[1]; P.sz = so[2];
+      P.dx = sd[0]; P.dy = sd[1]; P.dz = sd[2];
+    }
+    return P;
+  };
+  auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+  int4 rec = make_int4(-1, 0, 0, 0);
+  if (tid < n) rec = recs[lo + tid];
   if (n > 0) {
     u.s.cnt[2 * tid] = 0;
     u.s.cnt[2 * tid + 1] = 0;
-    __syncthreads();
   }
+  Payload P = fetch(rec, tid < n);
+  if (n > 0) lds_barrier();
   for (int base = 0; base < n; base += 256) {
-    const int e = base + tid;
+    const bool have = base + tid < n;
+    const bool have_next = base + 256 + tid < n;
+    int4 rec_next = make_int4(-1, 0, 0, 0);
+    if (have_next) rec_next = recs[lo + base + 256 + tid];
     int rowc[8], tk[8];
     float wc[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) { rowc[q] = -1; tk[q] = 0; wc[q] = 0.f; }
-    if (e < n) {
-      const int4 rec = recs[lo + e];                        // {kept index or -1, ray, step, density gradient}
+    if (have) {
       float* gp = u.s.g[tid];
-      if (rec.x >= 0) {
-        const float* src = g_feat + (int64_t)rec.x * C;
-        if constexpr (C % 4 == 0) {
+      if constexpr (C % 4 == 0) {
 #pragma unroll
-          for (int c = 0; c < C / 4; ++c) reinterpret_cast<float4*>(gp)[c] = reinterpret_cast<const float4*>(src)[c];
-        } else {
+        for (int c = 0; c < C / 4; ++c)
+          reinterpret_cast<float4*>(gp)[c] = make_float4(P.g[4 * c], P.g[4 * c + 1], P.g[4 * c + 2], P.g[4 * c + 3]);
+      } else {
 #pragma unroll
-          for (int c = 0; c < C; ++c) gp[c] = src[c];
-        }
-      } else {                                   // passed the alpha filter only: no feature gradient
-#pragma unroll
-        for (int c = 0; c < C; ++c) gp[c] = 0.f;
+        for (int c = 0; c < C; ++c) gp[c] = P.g[c];
       }
-      gp[C] = __int_as_float(rec.w);
-      float px, py, pz;
-      march_pos(rays_start, rays_dir, rec.y, G.stepdist, rec.z, px, py, pz);
+      gp[C] = P.gd;
+      const float dist = march_dist(G.stepdist, P.step);
+      const float px = fmaf(P.dx, dist, P.sx), py = fmaf(P.dy, dist, P.sy), pz = fmaf(P.dz, dist, P.sz);
       const TriSetup t = dvgo_tri_setup(px, py, pz, G.mnx, G.mny, G.mnz, G.mxx, G.mxy, G.mxz, G.X, G.Y, G.Z);
       const int li = t.i0 - (bx << DVGO_BRICK_LOG), lj = t.j0 - (by << DVGO_BRICK_LOG), lk = t.k0 - (bz << DVGO_BRICK_LOG);
 #pragma unroll
@@ -149,7 +191,8 @@ brick_accumulate_kernel(const int32_t* __restrict__ off, const int4* __restrict_
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
+    P = fetch(rec_next, have_next);               // payload of the next chunk: in flight until the next iteration
     // exclusive scan of the 512 counters: thread t owns voxels 2t and 2t + 1 from here on
     const int c0 = u.s.cnt[2 * tid], c1 = u.s.cnt[2 * tid + 1];
     const int s = c0 + c1;
@@ -160,17 +203,17 @@ brick_accumulate_kernel(const int32_t* __restrict__ off, const int4* __restrict_
       if (lane >= d) inc += o;
     }
     if (lane == 63) u.s.wsum[wave] = inc;
-    __syncthreads();
+    lds_barrier();
     int o0 = inc - s;
     for (int w = 0; w < wave; ++w) o0 += u.s.wsum[w];
     const int o1 = o0 + c0;
     u.s.cnt[2 * tid] = o0;
     u.s.cnt[2 * tid + 1] = o1;
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int q = 0; q < 8; ++q)
       if (rowc[q] >= 0) u.s.refs[u.s.cnt[rowc[q]] + tk[q]] = make_float2(wc[q], __int_as_float(tid));
-    __syncthreads();
+    lds_barrier();
     for (int k = 0; k < c0; ++k) {
       const float2 r = u.s.refs[o0 + k];
       const float* g = u.s.g[__float_as_int(r.y)];
@@ -185,7 +228,7 @@ brick_accumulate_kernel(const int32_t* __restrict__ off, const int4* __restrict_
     }
     u.s.cnt[2 * tid] = 0;
     u.s.cnt[2 * tid + 1] = 0;
-    __syncthreads();
+    lds_barrier();
   }
 
   // the finished tile, voxel-major, through LDS so that the global accesses below are coalesced
@@ -198,28 +241,60 @@ brick_accumulate_kernel(const int32_t* __restrict__ off, const int4* __restrict_
 
   const int x0 = bx << DVGO_BRICK_LOG, y0 = by << DVGO_BRICK_LOG, z0 = bz << DVGO_BRICK_LOG;
   if constexpr (C == 12) {
-    // 4 lanes per voxel: three float4 of features + the density scalar; 8 voxels in z = 384 contiguous bytes of k0
-    for (int idx = tid; idx < 512 * 4; idx += 256) {
-      const int row = idx >> 2, q = idx & 3;
-      const int gi = x0 + (row >> 6), gj = y0 + ((row >> 3) & 7), gk = z0 + (row & 7);
-      if (gi >= G.X || gj >= G.Y || gk >= G.Z) continue;
-      const int64_t vox = ((int64_t)gi * G.Y + gj) * G.Z + gk;
-      const float4 g = reinterpret_cast<const float4*>(u.tile[row])[q];
-      if (!ADAM) {
-        if (q < 3) reinterpret_cast<float4*>(grad_k0)[vox * 3 + q] = g;
-        else grad_density[vox] = g.x;
-      } else if (q < 3) {
-        if (A.masked_k && g.x == 0.f && g.y == 0.f && g.z == 0.f && g.w == 0.f) continue;
-        const int64_t i = vox * 3 + q;
-        float4 p = reinterpret_cast<float4*>(A.pk)[i], m = reinterpret_cast<float4*>(A.mk)[i], v = reinterpret_cast<float4*>(A.vk)[i];
-        if (A.masked_k) adam4<1>(p, g, m, v, A.ss_k, A.beta1, A.beta2, A.eps);
-        else adam4<0>(p, g, m, v, A.ss_k, A.beta1, A.beta2, A.eps);
-        reinterpret_cast<float4*>(A.pk)[i] = p;
-        reinterpret_cast<float4*>(A.mk)[i] = m;
-        reinterpret_cast<float4*>(A.vk)[i] = v;
-      } else {
-        if (A.masked_d) adam_one<1>(A.pd[vox], g.x, A.md[vox], A.vd[vox], 0.f, A.ss_d, A.beta1, A.beta2, A.eps);
-        else adam_one<0>(A.pd[vox], g.x, A.md[vox], A.vd[vox], 0.f, A.ss_d, A.beta1, A.beta2, A.eps);
+    // 4 lanes per voxel: three float4 of features + the density scalar; 8 voxels in z = 384 contiguous bytes of k0.
+    // 8 items per thread, handled 4 at a time with all loads of a batch issued before the first use.
+    float* __restrict__ pk = A.pk; float* __restrict__ mk = A.mk; float* __restrict__ vk = A.vk;
+    float* __restrict__ pd = A.pd; float* __restrict__ md = A.md; float* __restrict__ vd = A.vd;
+    const int gj0 = y0 + ((tid >> 5) & 7), gk0 = z0 + ((tid >> 2) & 7);
+    const bool ok_yz = (gj0 < G.Y) & (gk0 < G.Z);
+    const int64_t plane = (int64_t)G.Y * G.Z;
+    const int64_t vox0 = ((int64_t)x0 * G.Y + gj0) * G.Z + gk0;
+#pragma unroll
+    for (int batch = 0; batch < 2; ++batch) {
+      int64_t vox[4];
+      bool ok[4];
+      float4 g[4], p[4], m[4], v[4];
+#pragma unroll
+      for (int u4 = 0; u4 < 4; ++u4) {
+        // item tid + 256 * it is (row (tid >> 2) + 64 * it, quarter tid & 3): the x plane advances with `it`, y and z
+        // are the thread's own
+        const int it = batch * 4 + u4;
+        const int row = (tid >> 2) + 64 * it, q = tid & 3;
+        ok[u4] = ok_yz & (x0 + it < G.X);
+        vox[u4] = vox0 + (int64_t)it * plane;
+        g[u4] = reinterpret_cast<const float4*>(u.tile[row])[q];
+        if (ADAM && ok[u4]) {
+          if (q < 3) {
+            const int64_t i = vox[u4] * 3 + q;
+            p[u4] = reinterpret_cast<const float4*>(pk)[i];
+            m[u4] = reinterpret_cast<const float4*>(mk)[i];
+            v[u4] = reinterpret_cast<const float4*>(vk)[i];
+          } else {
+            p[u4].x = pd[vox[u4]]; m[u4].x = md[vox[u4]]; v[u4].x = vd[vox[u4]];
+          }
+        }
+      }
+#pragma unroll
+      for (int u4 = 0; u4 < 4; ++u4) {
+        if (!ok[u4]) continue;
+        const int q = (tid + 256 * (batch * 4 + u4)) & 3;       // == tid & 3
+        if (!ADAM) {
+          if (q < 3) reinterpret_cast<float4*>(grad_k0)[vox[u4] * 3 + q] = g[u4];
+          else grad_density[vox[u4]] = g[u4].x;
+        } else if (q < 3) {
+          if (A.masked_k && g[u4].x == 0.f && g[u4].y == 0.f && g[u4].z == 0.f && g[u4].w == 0.f) continue;
+          const int64_t i = vox[u4] * 3 + q;
+          if (A.masked_k) adam4<1>(p[u4], g[u4], m[u4], v[u4], A.ss_k, A.beta1, A.beta2, A.eps);
+          else adam4<0>(p[u4], g[u4], m[u4], v[u4], A.ss_k, A.beta1, A.beta2, A.eps);
+          reinterpret_cast<float4*>(pk)[i] = p[u4];
+          reinterpret_cast<float4*>(mk)[i] = m[u4];
+          reinterpret_cast<float4*>(vk)[i] = v[u4];
+        } else {
+          if (A.masked_d && g[u4].x == 0.f) continue;
+          if (A.masked_d) adam_one<1>(p[u4].x, g[u4].x, m[u4].x, v[u4].x, 0.f, A.ss_d, A.beta1, A.beta2, A.eps);
+          else adam_one<0>(p[u4].x, g[u4].x, m[u4].x, v[u4].x, 0.f, A.ss_d, A.beta1, A.beta2, A.eps);
+          pd[vox[u4]] = p[u4].x; md[vox[u4]] = m[u4].x; vd[vox[u4]] = v[u4].x;
+        }
       }
     }
   } else {

@@ -142,7 +142,11 @@ def test_adam_fused_into_the_brick_kernel_equals_dense_gradients_plus_masked_ada
         assert st['step'] == 3
         outs.append((m.density.detach().clone(), m.k0.detach().clone(), st['exp_avg'].clone(), st['exp_avg_sq'].clone(), p0))
     (d_a, k_a, m_a, v_a, p0), (d_b, k_b, m_b, v_b, _) = outs
-    assert torch.equal(d_a != p0[0], d_b != p0[0]) and torch.equal(k_a != p0[1], k_b != p0[1])
+    # the masked rule updates an element iff its gradient is not exactly 0: the two runs sum the same contributions in
+    # different orders, so the sets agree except where a sum of a few terms cancels to exactly 0.0f in one order and to
+    # a last-bit residue in the other (a 2^-24-ish event per element: a handful out of 53 M at full size, none at 48^3)
+    n_d, n_k = int(((d_a != p0[0]) != (d_b != p0[0])).sum()), int(((k_a != p0[1]) != (k_b != p0[1])).sum())
+    assert n_d <= 1e-6 * d_a.numel() + (0 if world < 100 else 2) and n_k <= 1e-6 * k_a.numel() + (0 if world < 100 else 2), (n_d, n_k)
     assert int((k_a != p0[1]).sum()) > 0
     # Adam normalises the step (lr 0.1 * m / sqrt(v)): where a gradient nearly cancels, summation-order noise is
     # amplified, so compare the moments tightly and the parameters with the usual Adam allowance
