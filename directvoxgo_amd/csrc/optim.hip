@@ -104,8 +104,8 @@ tv_kernel(const float* __restrict__ param, float* __restrict__ grad, float wy, f
 template <bool DENSE>
 __global__ void __launch_bounds__(DVGO_BLOCK)
 tv_rows_kernel(const float* __restrict__ param, float* __restrict__ grad, float wy, float wz, int R, int sK,
-               int I, int J, int64_t sC, int64_t sI, int64_t sJ) {
-  const int row = blockIdx.x;
+               int I, int J, int64_t sC, int64_t sI, int64_t sJ, int row0) {
+  const int row = row0 + blockIdx.x;
   const int ij = I * J;
   const int c = row / ij, rem = row - c * ij;
   const int i = rem / J, j = rem - i * J;
@@ -177,38 +177,54 @@ int dvgo_adam_rows(const float* G, int64_t n_vox, int row_stride, int C, float* 
   return 0;
 }
 
-int dvgo_total_variation_add_grad(const float* param, float* grad, float wx, float wy, float wz,
-                                  int64_t C, int64_t sz_i, int64_t sz_j, int64_t sz_k, int64_t sC,
-                                  int64_t sI, int64_t sJ, int64_t sK, int dense_mode, void* stream) {
+// i_lo / i_hi: the planes [i_lo, i_hi) of the first spatial axis whose gradient is touched (the whole grid: 0, sz_i).  A
+// data-parallel rank that owns one slab of the grid (train.py) adds the TV gradient of its slab only; the stencil still
+// reads the neighbouring planes of `param`, which every rank holds.
+int dvgo_total_variation_add_grad_slab(const float* param, float* grad, float wx, float wy, float wz,
+                                       int64_t C, int64_t sz_i, int64_t sz_j, int64_t sz_k, int64_t sC,
+                                       int64_t sI, int64_t sJ, int64_t sK, int dense_mode, int64_t i_lo, int64_t i_hi,
+                                       void* stream) {
   (void)wx;
-  if (C < 0 || sz_i < 0 || sz_j < 0 || sz_k < 0) return DVGO_EINVAL;
+  if (C < 0 || sz_i < 0 || sz_j < 0 || sz_k < 0 || i_lo < 0 || i_hi > sz_i || i_lo > i_hi) return DVGO_EINVAL;
   const int64_t N = C * sz_i * sz_j * sz_k;
-  if (N == 0) return 0;
+  if (N == 0 || i_lo == i_hi) return 0;
   if (!param || !grad) return DVGO_EINVAL;
   if (!dvgo_fits(N)) return DVGO_ERANGE;
   wy /= 6; wz /= 6;   // total_variation_kernel.cu:46-48
   const bool cl = (sC == 1 && C > 1);
   hipStream_t s = (hipStream_t)stream;
+  const bool whole = (i_lo == 0 && i_hi == sz_i);
   // dense layouts: channels-last (sC == 1, sK == C) or channel-first (sK == 1), any C
   const bool rows_cl = (sC == 1 && sK == C && sJ == sz_k * C && sI == sz_j * sz_k * C);
   const bool rows_cf = (sK == 1 && sJ == sz_k && sI == sz_j * sz_k && (C == 1 || sC == sz_i * sz_j * sz_k));
   const int64_t n_rows = rows_cl ? sz_i * sz_j : C * sz_i * sz_j;
   const int64_t R = rows_cl ? sz_k * C : sz_k;
-  if ((rows_cl || rows_cf) && n_rows < ((int64_t)1 << 31) && R < ((int64_t)1 << 30)) {
+  if ((rows_cl || (rows_cf && (whole || C == 1))) && n_rows < ((int64_t)1 << 31) && R < ((int64_t)1 << 30)) {
     const int threads = R >= 256 ? 256 : (R > 128 ? 256 : (R > 64 ? 128 : 64));
+    // rows are (i, j) pairs (channels-last, or C == 1), i outermost: a slab is a contiguous range of rows
+    const int row0 = whole ? 0 : (int)(i_lo * sz_j);
+    const int rows = whole ? (int)n_rows : (int)((i_hi - i_lo) * sz_j);
     if (dense_mode)
-      tv_rows_kernel<true><<<(int)n_rows, threads, 0, s>>>(param, grad, wy, wz, (int)R, (int)sK, (int)sz_i, (int)sz_j, sC, sI, sJ);
+      tv_rows_kernel<true><<<rows, threads, 0, s>>>(param, grad, wy, wz, (int)R, (int)sK, (int)sz_i, (int)sz_j, sC, sI, sJ, row0);
     else
-      tv_rows_kernel<false><<<(int)n_rows, threads, 0, s>>>(param, grad, wy, wz, (int)R, (int)sK, (int)sz_i, (int)sz_j, sC, sI, sJ);
+      tv_rows_kernel<false><<<rows, threads, 0, s>>>(param, grad, wy, wz, (int)R, (int)sK, (int)sz_i, (int)sz_j, sC, sI, sJ, row0);
     DVGO_LAUNCH_CHECK();
     return 0;
   }
+  if (!whole) return DVGO_ERANGE;          // slabs are built for the row layouts above
   if (dense_mode)
     tv_kernel<true><<<dvgo_blocks(N, DVGO_BLOCK), DVGO_BLOCK, 0, s>>>(param, grad, wy, wz, C, sz_i, sz_j, sz_k, sC, sI, sJ, sK, cl, N);
   else
     tv_kernel<false><<<dvgo_blocks(N, DVGO_BLOCK), DVGO_BLOCK, 0, s>>>(param, grad, wy, wz, C, sz_i, sz_j, sz_k, sC, sI, sJ, sK, cl, N);
   DVGO_LAUNCH_CHECK();
   return 0;
+}
+
+int dvgo_total_variation_add_grad(const float* param, float* grad, float wx, float wy, float wz,
+                                  int64_t C, int64_t sz_i, int64_t sz_j, int64_t sz_k, int64_t sC,
+                                  int64_t sI, int64_t sJ, int64_t sK, int dense_mode, void* stream) {
+  return dvgo_total_variation_add_grad_slab(param, grad, wx, wy, wz, C, sz_i, sz_j, sz_k, sC, sI, sJ, sK, dense_mode, 0,
+                                            sz_i, stream);
 }
 
 }  // extern "C"

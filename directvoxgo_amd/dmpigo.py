@@ -110,17 +110,17 @@ class DirectMPIGO(nn.Module):
                                     xyz_min=self._xyz_min_cpu, xyz_max=self._xyz_max_cpu).to(self.density.device)
         self._cfg_cache = {}
 
-    def density_total_variation_add_grad(self, weight, dense_mode):
+    def density_total_variation_add_grad(self, weight, dense_mode, x_range=None):
         """lib/dmpigo.py:147-151"""
         wxy = weight * float(self.world_size[:2].max()) / 128
         wz = weight * self.mpi_depth / 128
-        total_variation_add_grad(self.density, self.density.grad, wxy, wxy, wz, dense_mode)
+        total_variation_add_grad(self.density, self.density.grad, wxy, wxy, wz, dense_mode, x_range)
 
-    def k0_total_variation_add_grad(self, weight, dense_mode):
+    def k0_total_variation_add_grad(self, weight, dense_mode, x_range=None):
         """lib/dmpigo.py:153-157"""
         wxy = weight * float(self.world_size[:2].max()) / 128
         wz = weight * self.mpi_depth / 128
-        total_variation_add_grad(self.k0, self.k0.grad, wxy, wxy, wz, dense_mode)
+        total_variation_add_grad(self.k0, self.k0.grad, wxy, wxy, wz, dense_mode, x_range)
 
     def activate_density(self, density, interval=None):
         interval = interval if interval is not None else self.voxel_size_ratio

@@ -248,15 +248,15 @@ class DirectVoxGO(nn.Module):
                 L.call('dvgo_view_count_commit', ptr(acc), ptr(count), _i64(X * Y * Z), st)
         return count
 
-    def density_total_variation_add_grad(self, weight, dense_mode):
+    def density_total_variation_add_grad(self, weight, dense_mode, x_range=None):
         """lib/dvgo.py:297-300"""
         w = weight * float(self.world_size.max()) / 128
-        total_variation_add_grad(self.density, self.density.grad, w, w, w, dense_mode)
+        total_variation_add_grad(self.density, self.density.grad, w, w, w, dense_mode, x_range)
 
-    def k0_total_variation_add_grad(self, weight, dense_mode):
+    def k0_total_variation_add_grad(self, weight, dense_mode, x_range=None):
         """lib/dvgo.py:302-305"""
         w = weight * float(self.world_size.max()) / 128
-        total_variation_add_grad(self.k0, self.k0.grad, w, w, w, dense_mode)
+        total_variation_add_grad(self.k0, self.k0.grad, w, w, w, dense_mode, x_range)
 
     # ------------------------------------------------------------------ op wrappers
     def activate_density(self, density, interval=None):

@@ -167,6 +167,27 @@ class MaskedAdam(torch.optim.Optimizer):
                    _flt(b1), _flt(b2), _flt(gk['eps']), stream_of(k0))
 
     @torch.no_grad()
+    def step_shard(self, p, flat_p, flat_g, lo, hi):
+        """The update of `step()` for the elements [lo, hi) of parameter `p` in memory order (`flat_p` / `flat_g`: flat
+        views of the parameter's and the gradient's memory).  Data parallel: each rank updates the slab of a grid it
+        owns from the reduce-scattered gradient (train.py); the element-wise rule and the dispatch order
+        (per-voxel lr -> masked -> plain, lib/masked_adam.py:60-71) are those of `step()`.  The moments stay full-size
+        tensors of which a rank only ever touches its own slab."""
+        group = self._group_of(p)
+        st = self._state_of(p)
+        st['step'] += 1
+        b1, b2 = group['betas']
+        use_perlr = self.per_lr is not None and p.shape == self.per_lr.shape
+        if use_perlr:
+            self.per_lr = self._like(p, self.per_lr)
+        mode = 2 if use_perlr else (1 if group.get('skip_zero_grad', False) else 0)
+        from .train import flat_view
+        m, v = flat_view(st['exp_avg']), flat_view(st['exp_avg_sq'])
+        pl = flat_view(self.per_lr)[lo:hi] if use_perlr else None
+        adam_upd(flat_p[lo:hi], flat_g[lo:hi], m[lo:hi], v[lo:hi], st['step'], b1, b2, group['lr'], group['eps'], mode=mode,
+                 perlr=pl)
+
+    @torch.no_grad()
     def step(self):
         for group in self.param_groups:
             b1, b2 = group['betas']

@@ -229,15 +229,17 @@ def segment_coo(src, index, out, reduce='sum'):
     return _SegmentSum.apply(src.contiguous(), index, out)
 
 
-def total_variation_add_grad(param, grad, wx, wy, wz, dense_mode):
+def total_variation_add_grad(param, grad, wx, wy, wz, dense_mode, x_range=None):
     """total_variation_cuda.total_variation_add_grad (lib/cuda/total_variation.cpp:16-24);
-    in place on ``grad``; param/grad [1,C,X,Y,Z] sharing one (dense) stride pattern."""
+    in place on ``grad``; param/grad [1,C,X,Y,Z] sharing one (dense) stride pattern.
+    ``x_range=(lo, hi)``: only the planes lo <= x < hi (the slab a data-parallel rank owns)."""
     if not (param.is_cuda and grad.is_cuda):
         raise RuntimeError('param must be a CUDA tensor')
     if param.stride() != grad.stride():
         raise RuntimeError('param and grad must share strides')
     C, X, Y, Z, sC, sX, sY, sZ = _grid_geom(param)
+    lo, hi = (0, X) if x_range is None else x_range
     with L.device_of(param):
-        L.call('dvgo_total_variation_add_grad', ptr(param), ptr(grad), _flt(float(wx)), _flt(float(wy)),
+        L.call('dvgo_total_variation_add_grad_slab', ptr(param), ptr(grad), _flt(float(wx)), _flt(float(wy)),
                _flt(float(wz)), _i64(C), _i64(X), _i64(Y), _i64(Z), _i64(sC), _i64(sX), _i64(sY), _i64(sZ),
-               _int(1 if dense_mode else 0), stream_of(param))
+               _int(1 if dense_mode else 0), _i64(lo), _i64(hi), stream_of(param))

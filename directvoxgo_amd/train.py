@@ -128,8 +128,11 @@ class TrainStep:
     """One optimisation step on one batch of rays; ``world_size > 1`` shards the batch by rank."""
 
     def __init__(self, model, cfg_train, render_kwargs, optimizer=None, process_group=None, fused_loss=True,
-                 overlap_wgrad=True, touched_reduce=True, rows_adam=True, track_mse=False):
+                 overlap_wgrad=True, touched_reduce=True, rows_adam=True, track_mse=False, shard_grids=True):
         self.model = model
+        # data parallel, dense scenes: reduce-scatter the grid gradients, update only the owned slab, all-gather the
+        # parameters (see _sharded_*); False = plain all-reduce + full update on every rank
+        self.shard_grids = shard_grids
         # weight_main * mse of the step, the quantity run.py:378 turns into the logged PSNR (before the entropy and
         # per-point terms are added); kept on the device, no sync
         self.track_mse = track_mse
@@ -152,8 +155,8 @@ class TrainStep:
         self._small = [p for n, p in model.named_parameters() if n not in ('density', 'k0') and p.requires_grad]
 
     def reduce_grids_async(self):
-        """Start the sum of the per-rank grid gradients (section 8e): two large collectives, in place on the
-        gradients' own memory.  Returns the handles to wait on."""
+        """Sparse scenes: start the compacted touched-voxel reduction (see _reduce_touched); returns its handle, or []
+        when the dense path (sharded reduce-scatter / all-reduce) has to take the step."""
         works = []
         if self.world == 1:
             return works
@@ -165,6 +168,11 @@ class TrainStep:
                 pending = self._reduce_touched(*rd) if rd is not None else None
                 if pending is not None:
                     return [pending]
+        return works
+
+    def _all_reduce_grids(self):
+        """Plain sum of the full grid gradients on every rank (the fallback when the grids cannot be sharded)."""
+        works = []
         for p in (self.model.density, self.model.k0):
             if p.grad is not None:
                 flat = flat_view(p.grad)
@@ -219,6 +227,47 @@ class TrainStep:
                     rows[idx] = compact[:, :C]
                     dflat[idx] = compact[:, C]
         return _Pending()
+
+    # ------------------------------------------------------------------------------------------------------------
+    # Dense scenes (every voxel has a gradient: the roofline case): a plain all-reduce moves 2 (P-1)/P x 213 MB per rank
+    # AND leaves every rank sweeping all 53 M elements through Adam.  Instead (ZeRO-1 style, SURVEY.md section 5):
+    #   reduce_scatter   rank r receives the SUM of the gradient of the X-planes [r X/P, (r+1) X/P) -- in place, the slab
+    #                    is a contiguous range of the gradient's memory (channels-last / C == 1: X is the outermost axis)
+    #   TV + Adam        on that slab only (1/P of the optimizer's traffic; the TV stencil reads the replicated params)
+    #   all_gather       the updated parameter slabs, in place in the parameters
+    # Same bytes on the wire as the all-reduce ((P-1)/P x 213 MB out and in per rank and phase, spread over all xGMI
+    # links by RCCL), 1/P of the optimizer work, and the parameters -- not the gradients -- are what ends up replicated.
+    # ------------------------------------------------------------------------------------------------------------
+    def _grid_shards(self):
+        """[(param, flat param, flat grad, lo, hi, (x_lo, x_hi))] for the grids when the sharded update applies."""
+        if not (self.shard_grids and self.world > 1 and hasattr(self.optimizer, 'step_shard')):
+            return None
+        rank = dist.get_rank(self.pg)
+        out = []
+        for p in (getattr(self.model, 'density', None), getattr(self.model, 'k0', None)):
+            if not isinstance(p, nn.Parameter) or p.grad is None or p.dim() != 5:
+                return None
+            x_outermost = p.shape[1] == 1 and p.is_contiguous() or p.is_contiguous(memory_format=torch.channels_last_3d)
+            fp, fg = flat_view(p.data), flat_view(p.grad)
+            X = p.shape[2]
+            if not x_outermost or fp is None or fg is None or p.grad.stride() != p.stride() or X % self.world != 0:
+                return None
+            n = fp.numel() // self.world
+            out.append((p, fp, fg, rank * n, (rank + 1) * n, (rank * (X // self.world), (rank + 1) * (X // self.world))))
+        return out
+
+    def _sharded_reduce_start(self, shards):
+        return [dist.reduce_scatter_tensor(fg[lo:hi], fg, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                for _, _, fg, lo, hi, _ in shards]
+
+    def _sharded_update(self, shards):
+        """Adam on the owned slabs, then the parameters travel.  Returns the all-gather handles."""
+        works = []
+        for p, fp, fg, lo, hi, _ in shards:
+            self.optimizer.step_shard(p, fp, fg, lo, hi)
+            p.grad = None                      # consumed: optimizer.step() below skips the grids
+            works.append(dist.all_gather_into_tensor(fp, fp[lo:hi], group=self.pg, async_op=True))
+        return works
 
     def reduce_small(self):
         """One flat bucket for the handful of MLP gradients."""
@@ -275,17 +324,25 @@ class TrainStep:
                 k0.grad = gk if k0.grad is None else k0.grad + gk
             cap.G = None
         works = self.reduce_grids_async()
+        shards = None
+        if self.world > 1 and not works:            # (the compacted touched-voxel reduction took the sparse case)
+            shards = self._grid_shards()
+            works = self._sharded_reduce_start(shards) if shards else self._all_reduce_grids()
         deferred.flush()
         self.reduce_small()
         for wk in works:
             wk.wait()
         if cfg['tv_after'] < global_step < cfg['tv_before'] and global_step % cfg['tv_every'] == 0:   # run.py:389-395
             dense = global_step < cfg['tv_dense_before']
+            xr = {'x_range': shards[0][5]} if shards else {}      # a rank that owns a slab adds the TV gradient of that slab
             if cfg['weight_tv_density'] > 0:
-                model.density_total_variation_add_grad(cfg['weight_tv_density'] / n_global, dense)
+                model.density_total_variation_add_grad(cfg['weight_tv_density'] / n_global, dense, **xr)
             if cfg['weight_tv_k0'] > 0:
-                model.k0_total_variation_add_grad(cfg['weight_tv_k0'] / n_global, dense)
+                model.k0_total_variation_add_grad(cfg['weight_tv_k0'] / n_global, dense, **xr)
+        gathers = self._sharded_update(shards) if shards else []
         self.optimizer.step()
+        for wk in gathers:
+            wk.wait()
         for group in self.optimizer.param_groups:                                                  # run.py:401-406
             group['lr'] = group['lr'] * self.decay_factor
         return loss.detach()

@@ -391,6 +391,13 @@ int dvgo_total_variation_add_grad(const float* param, float* grad, float wx, flo
                                   int64_t C, int64_t sz_i, int64_t sz_j, int64_t sz_k,
                                   int64_t sC, int64_t sI, int64_t sJ, int64_t sK,
                                   int dense_mode, void* stream);
+/* The same, restricted to the planes [i_lo, i_hi) of the first spatial axis (only their `grad` is touched; `param` is
+ * read one plane beyond on either side).  For a data-parallel rank that owns one slab of the grid.  Needs a layout whose
+ * outermost memory axis is that spatial axis (channels-last, or C == 1), else DVGO_ERANGE. */
+int dvgo_total_variation_add_grad_slab(const float* param, float* grad, float wx, float wy, float wz,
+                                       int64_t C, int64_t sz_i, int64_t sz_j, int64_t sz_k, int64_t sC,
+                                       int64_t sI, int64_t sJ, int64_t sK, int dense_mode, int64_t i_lo, int64_t i_hi,
+                                       void* stream);
 
 /* ---------------------------------------------------------------------------------
  * Harness glue (row H3): fused training loss, view-direction embedding, multi-tensor Adam.

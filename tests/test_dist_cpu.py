@@ -25,8 +25,8 @@ class ToyModel(nn.Module):
     def __init__(self, S=6):
         super().__init__()
         g = torch.Generator().manual_seed(5)
-        self.density = nn.Parameter(torch.randn(1, 1, 5, 5, 5, generator=g))
-        self.k0 = nn.Parameter((torch.randn(1, 6, 5, 5, 5, generator=g) * 0.3).contiguous(memory_format=torch.channels_last_3d))
+        self.density = nn.Parameter(torch.randn(1, 1, 6, 5, 5, generator=g))
+        self.k0 = nn.Parameter((torch.randn(1, 6, 6, 5, 5, generator=g) * 0.3).contiguous(memory_format=torch.channels_last_3d))
         self.rgbnet = nn.Sequential(nn.Linear(6, 8), nn.ReLU(), nn.Linear(8, 3))
         for p in self.rgbnet.parameters():
             p.data = torch.randn(p.shape, generator=g) * 0.3
@@ -56,10 +56,63 @@ def make_batch(n):
     return ro, rd, rd / rd.norm(dim=-1, keepdim=True), torch.rand(n, 3, generator=g)
 
 
+class TorchMaskedAdam(torch.optim.Optimizer):
+    """MaskedAdam's interface (param-group key `skip_zero_grad`, `step`, `step_shard`) on torch CPU ops
+    (oracle/torch_cpu.adam_step = lib/masked_adam.py:39-71 over adam_upd_kernel.cu:8-58): the stand-in that lets the
+    sharded data-parallel update of TrainStep run without a GPU."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.99), eps=1e-8):
+        super().__init__(params, {'lr': lr, 'betas': betas, 'eps': eps})
+
+    def _st(self, p):
+        st = self.state[p]
+        if not st:
+            st.update(step=0, exp_avg=torch.zeros_like(p, memory_format=torch.preserve_format),
+                      exp_avg_sq=torch.zeros_like(p, memory_format=torch.preserve_format))
+        return st
+
+    def _group_of(self, p):
+        return next(g for g in self.param_groups if any(q is p for q in g['params']))
+
+    @torch.no_grad()
+    def step(self):
+        from oracle.torch_cpu import adam_step
+        for g in self.param_groups:
+            for p in g['params']:
+                if p.grad is None:
+                    continue
+                st = self._st(p)
+                st['step'] += 1
+                adam_step(p.data, p.grad, st['exp_avg'], st['exp_avg_sq'], st['step'], g['lr'], mode=1 if g.get('skip_zero_grad') else 0)
+
+    @torch.no_grad()
+    def step_shard(self, p, flat_p, flat_g, lo, hi):
+        from directvoxgo_amd.train import flat_view
+        from oracle.torch_cpu import adam_step
+        g, st = self._group_of(p), self._st(p)
+        st['step'] += 1
+        adam_step(flat_p[lo:hi], flat_g[lo:hi], flat_view(st['exp_avg'])[lo:hi], flat_view(st['exp_avg_sq'])[lo:hi], st['step'],
+                  g['lr'], mode=1 if g.get('skip_zero_grad') else 0)
+
+
 def run_steps(model, batch, rank, world, n_steps=3, mode='dense'):
     cfg = dict(FINE_TRAIN, weight_entropy_last=0.01, weight_rgbper=0.05)
-    opt = torch.optim.SGD(model.parameters(), lr=0.5)
-    step = TrainStep(model, cfg, dict(bg=1), optimizer=opt, touched_reduce=(mode != 'dense'))
+    if mode in ('sharded', 'sharded_off'):
+        # Adam with the masked rule on the grids, the sharded update on (reduce-scatter -> slab Adam -> all-gather)
+        # or off (all-reduce -> full Adam on every rank)
+        opt = TorchMaskedAdam([{'params': [model.density], 'lr': 0.1, 'skip_zero_grad': True},
+                               {'params': [model.k0], 'lr': 0.1, 'skip_zero_grad': True},
+                               {'params': list(model.rgbnet.parameters()), 'lr': 1e-2}])
+        step = TrainStep(model, cfg, dict(bg=1), optimizer=opt, touched_reduce=False, shard_grids=(mode == 'sharded'))
+        step.sharded_steps = 0
+        orig = step._sharded_update
+        def counted(shards):
+            step.sharded_steps += 1
+            return orig(shards)
+        step._sharded_update = counted
+    else:
+        opt = torch.optim.SGD(model.parameters(), lr=0.5)
+        step = TrainStep(model, cfg, dict(bg=1), optimizer=opt, touched_reduce=(mode != 'dense'))
     if mode == 'touched':
         step.TOUCHED_MAX = 2.0            # always take the compact (touched-voxel) reduction
     elif mode == 'adaptive':
@@ -69,6 +122,10 @@ def run_steps(model, batch, rank, world, n_steps=3, mode='dense'):
     losses = []
     for s in range(n_steps):
         losses.append(step(*shard, global_step=s))
+    if mode == 'sharded' and world > 1:
+        assert step.sharded_steps == n_steps                    # the slab path really ran
+    if mode == 'sharded_off':
+        assert step.sharded_steps == 0
     return torch.stack(losses)
 
 
@@ -96,11 +153,12 @@ def _free_port():
 
 
 @pytest.mark.timeout(120)
-@pytest.mark.parametrize('mode', ['dense', 'touched', 'adaptive'])
+@pytest.mark.parametrize('mode', ['dense', 'touched', 'adaptive', 'sharded', 'sharded_off'])
 def test_two_ranks_equal_one_process(mode):
-    """`touched`: the grid gradients travel as the compacted union of the voxels either rank touched."""
+    """`touched`: the grid gradients travel as the compacted union of the voxels either rank touched.
+    `sharded`: reduce-scatter of the grid gradients, Adam on the owned X-slab only, all-gather of the parameters."""
     ref_model = ToyModel()
-    ref_losses = run_steps(ref_model, make_batch(32), 0, 1)
+    ref_losses = run_steps(ref_model, make_batch(32), 0, 1, mode=mode if mode.startswith('sharded') else 'dense')
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()

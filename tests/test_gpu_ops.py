@@ -442,3 +442,26 @@ def test_deferred_wgrad_gives_identical_parameter_gradients():
         # the per-workgroup partial sums are combined with float atomics: two runs differ by summation order, i.e. by
         # rounding relative to the LARGEST terms of a sum, not to a result that may have cancelled to near zero
         assert float((p.grad - r).abs().max()) <= 1e-5 * float(r.abs().max())
+
+
+@pytest.mark.parametrize('cl,C', [(True, 12), (True, 9), (False, 1)])
+@pytest.mark.parametrize('dense', [True, False])
+def test_total_variation_slab_by_slab_equals_whole_grid(cl, C, dense):
+    """dvgo_total_variation_add_grad_slab: the TV gradient added plane-range by plane-range (what the data-parallel ranks
+    do, each on the slab it owns) is the TV gradient of the whole grid, bit for bit."""
+    from directvoxgo_amd.ops import total_variation_add_grad
+    torch.manual_seed(2)
+    p = torch.randn(1, C, 13, 9, 11, device='cuda')
+    g = torch.randn(1, C, 13, 9, 11, device='cuda') * (torch.rand(1, C, 13, 9, 11, device='cuda') < 0.5)
+    if cl:
+        p, g = p.contiguous(memory_format=torch.channels_last_3d), g.contiguous(memory_format=torch.channels_last_3d)
+    whole = g.clone()
+    total_variation_add_grad(p, whole, 0.3, 0.3, 0.7, dense)
+    parts = g.clone()
+    for lo, hi in ((0, 4), (4, 5), (5, 13)):
+        total_variation_add_grad(p, parts, 0.3, 0.3, 0.7, dense, x_range=(lo, hi))
+    assert torch.equal(whole, parts)
+    only = g.clone()
+    total_variation_add_grad(p, only, 0.3, 0.3, 0.7, dense, x_range=(4, 5))
+    assert torch.equal(only[:, :, :4], g[:, :, :4]) and torch.equal(only[:, :, 5:], g[:, :, 5:])
+    assert torch.equal(only[:, :, 4:5], whole[:, :, 4:5])

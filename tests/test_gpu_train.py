@@ -264,23 +264,36 @@ def _dp_run(rank, world, mode, n_steps=3):
                     fast_color_thres=1e-4, rgbnet_dim=12, rgbnet_width=128, rgbnet_direct=True).cuda()
     with torch.no_grad():
         m.density.copy_(sc['density']); m.k0.copy_(sc['k0']); m.mask_cache.mask.copy_(sc['mask'])
-    step = TrainStep(m, dict(FINE_TRAIN), dict(near=sc['near'], far=sc['far'], bg=1, stepsize=0.5),
-                     touched_reduce=(mode == 'touched'))
+    cfg = dict(FINE_TRAIN)
+    if mode == 'sharded_tv':               # total variation on both grids, sparse mode: it branches on the REDUCED gradient
+        cfg.update(tv_before=1e9, tv_dense_before=0, weight_tv_density=1e-4, weight_tv_k0=1e-4)
+    step = TrainStep(m, cfg, dict(near=sc['near'], far=sc['far'], bg=1, stepsize=0.5),
+                     touched_reduce=(mode == 'touched'), shard_grids=(mode != 'allreduce'))
     if mode == 'touched':
         step.TOUCHED_MAX = 2.0
+    if world > 1 and mode in ('dense', 'sharded_tv'):
+        assert step._grid_shards is not None
+        ran = []
+        orig = step._sharded_update
+        step._sharded_update = lambda shards: (ran.append(1), orig(shards))[1]
+        step._ran_sharded = ran
     n = 2048 // world
     shard = tuple(sc[k][rank * n:(rank + 1) * n] for k in ('rays_o', 'rays_d', 'viewdirs', 'target'))
-    losses = [float(step(*shard, global_step=s)) for s in range(n_steps)]
+    losses = [float(step(*shard, global_step=1 + s)) for s in range(n_steps)]
     torch.cuda.synchronize()
+    if hasattr(step, '_ran_sharded'):
+        assert len(step._ran_sharded) == n_steps        # reduce-scatter -> slab TV + Adam -> all-gather really ran
     return {k: v.detach().clone() for k, v in m.state_dict().items() if v.is_floating_point()}, losses
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize('mode', ['dense', 'touched'])
+@pytest.mark.parametrize('mode', ['dense', 'allreduce', 'touched', 'sharded_tv'])
 def test_two_ranks_on_one_gpu_equal_one_process(mode):
     """The product path under data parallelism: two ranks (gloo, both on this GPU), each marching half
-    of the batch with the HIP kernels, reach the parameters of one process on the whole batch -- with the dense grid
-    all-reduce and with the compacted touched-voxel reduction."""
+    of the batch with the HIP kernels, reach the parameters of one process on the whole batch -- `dense`: reduce-scatter of
+    the grid gradients, Adam on the owned X-slab, all-gather of the parameters; `sharded_tv`: the same with the sparse
+    total-variation gradient added per slab; `allreduce`: the unsharded fallback; `touched`: the compacted
+    touched-voxel reduction."""
     import socket
     import torch.multiprocessing as mp
     ref_params, ref_losses = _dp_run(0, 1, mode)
@@ -313,6 +326,7 @@ def test_adam_from_gradient_rows_equals_dense_path():
     outs = []
     saved = fused_mod.COMBINED_MIN_RATIO
     fused_mod.COMBINED_MIN_RATIO = 1e9           # the combined-rows backward on this small scene
+    fused_mod.BRICK_SCATTER = False              # (the default brick scatter fuses Adam itself: test_gpu_brick.py)
     try:
         for rows in (True, False):
             torch.manual_seed(4)
@@ -329,6 +343,7 @@ def test_adam_from_gradient_rows_equals_dense_path():
                          st[m.k0]['exp_avg_sq'].clone(), st[m.density]['exp_avg'].clone(), st[m.k0]['step'], st[m.density]['step']])
     finally:
         fused_mod.COMBINED_MIN_RATIO = saved
+        fused_mod.BRICK_SCATTER = True
     a, b = outs
     assert a[5] == b[5] == 3 and a[6] == b[6] == 3
     assert torch.equal(a[2] != 0, b[2] != 0)                           # same voxels ever touched
