@@ -40,7 +40,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/
 HOT_KERNELS = ['dvgo_sample_pts_prepare', 'dvgo_march_density', 'dvgo_exclusive_scan_i32', 'dvgo_march_gather',
                'dvgo_march_composite', 'dvgo_march_composite_bwd', 'dvgo_march_feat_bwd', 'dvgo_march_density_bwd',
                'dvgo_grid_grad_split', 'dvgo_adam_rows', 'dvgo_adam_upd', 'dvgo_shade_fwd', 'dvgo_shade_bwd', 'dvgo_shade_wgrad',
-               'dvgo_brick_scan', 'dvgo_brick_accumulate']
+               'dvgo_brick_scan', 'dvgo_march_scans', 'dvgo_brick_accumulate']
 
 
 def algorithmic_bytes(name, N, M_d, M2, M_k, C, n_grid):
@@ -60,6 +60,7 @@ def algorithmic_bytes(name, N, M_d, M2, M_k, C, n_grid):
         'dvgo_adam_rows': None,                                             # per call: 64 B row + 6 x 52 B of p / m / v per voxel
         'dvgo_adam_upd': None,                                              # per call: 28 B / element (dense)
         'dvgo_brick_scan': None,
+        'dvgo_march_scans': None,
         # owner-computes scatter with the Adam update applied from the LDS tile: the scatter's algorithmic bytes
         # (8 corner rows of C + 1 floats per sample + the sample's gradient row) + Adam's 6 x (C + 1) x 4 B
         # (p, m, v read and written) per voxel
@@ -72,10 +73,10 @@ def algorithmic_bytes(name, N, M_d, M2, M_k, C, n_grid):
 
 
 def pmc_traffic(workload, world, n_rays):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*/pmc_traffic.json), when they
-    were collected for this exact workload; None otherwise."""
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*/pmc_traffic.json, the newest round
+    that has them for this exact workload) and the file they came from; ({}, None) otherwise."""
     import glob
-    best = {}
+    best, src = {}, None
     for f in sorted(glob.glob(os.path.join(REPO, 'profiles', '*', 'pmc_traffic.json'))):
         try:
             d = json.load(open(f))
@@ -83,7 +84,8 @@ def pmc_traffic(workload, world, n_rays):
             continue
         if d.get('workload') == workload and d.get('grid') == world and d.get('rays') == n_rays:
             best = {k: v['hbm_bytes'] for k, v in d['kernels'].items()}
-    return best
+            src = os.path.relpath(f, REPO)
+    return best, src
 
 
 def build(workload, world, n_rays, device, seed):
@@ -276,7 +278,9 @@ def cpu_baseline(sc_cpu, m, rk, n_rays_total, sample_rays):
     import copy
     from oracle import torch_cpu as TC
     model, usable = _cpu_info()
-    threads = int(os.environ.get('DVGO_CPU_THREADS', '0')) or usable
+    # a 1-GPU box owns a 16-CPU share of its host (256 logical CPUs visible): more threads than that only fight each other
+    # (256 threads: 85 rays/s; the figure is what `cores` says was used).  DVGO_CPU_THREADS overrides.
+    threads = int(os.environ.get('DVGO_CPU_THREADS', '0')) or min(usable, 16)
     torch.set_num_threads(threads)
     out = {}
     # ---------------- config 2, roofline case, `sample_rays` rays
@@ -320,7 +324,7 @@ def cpu_baseline(sc_cpu, m, rk, n_rays_total, sample_rays):
         perlr = torch.rand_like(d1)                                         # view-count learning rate (run.py:311-320)
         rays1 = (sc1['rays_o'], sc1['rays_d'], sc1['viewdirs'])
         _torch_cpu_step(P1, d1, c1, None, None, rays1, sc1['target'], st1, 1, (0.1, 0.1, 0), (2, 0, 0), perlr, 0.01, 0.1)   # warm-up
-        reps = 3
+        reps = 20
         t0 = time.perf_counter()
         for i in range(reps):
             M1 = _torch_cpu_step(P1, d1, c1, None, None, rays1, sc1['target'], st1, 2 + i, (0.1, 0.1, 0), (2, 0, 0), perlr, 0.01, 0.1)
@@ -332,7 +336,7 @@ def cpu_baseline(sc_cpu, m, rk, n_rays_total, sample_rays):
         out['config1'] = {'error': repr(exc)}
     # ---------------- the scalar C port, one thread
     try:
-        out['c_port_1_thread'] = _c_port_baseline(sc_cpu, m, rk, n_rays_total, min(sample_rays, 1024))
+        out['c_port_1_thread'] = _c_port_baseline(sc_cpu, m, rk, n_rays_total, min(sample_rays, 4096))
     except Exception as exc:
         out['c_port_1_thread'] = {'error': repr(exc)}
     torch.set_num_threads(threads)
@@ -352,7 +356,10 @@ def main():
                          "(BASELINE configs[2]: one 8192-ray batch sharded over 8 GPUs)")
     ap.add_argument('--no-secondary', action='store_true', help='skip the lego-like secondary measurement')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample-rays', type=int, default=2048)
+    ap.add_argument('--cpu-sample-rays', type=int, default=8192)
+    ap.add_argument('--single-stream', action='store_true',
+                    help='timed region without the second-stream overlap of the colour-head weight gradients: every launch '
+                         'of a kernel then runs alone, so rocprofv3 --stats averages agree with the HIP-event averages')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend for N > 1 ('nccl' = RCCL on ROCm)")
     args = ap.parse_args()
 
@@ -384,7 +391,7 @@ def main():
         rk = dict(near=sc['near'], far=sc['far'], bg=1, stepsize=sc['stepsize'])
         pool = ray_pool(workload, float(sc['xyz_max'][0]), args.rays, device, base_seed=777 + 1000 * rank, n_batches=4)
         M0, M_d, M_k = count_samples(m, pool[0], rk)
-        step = TrainStep(m, dict(FINE_TRAIN), rk)
+        step = TrainStep(m, dict(FINE_TRAIN), rk, overlap_wgrad=not args.single_stream)
         dt, prof = timed_region(step, pool, steps, warmup, world, profile)
         end_counts = count_samples(m, pool[0], rk)          # the optimizer moves the scene: how far did the workload drift?
         return sc, m, rk, dt, prof, (M0, M_d, M_k), end_counts
@@ -409,19 +416,21 @@ def main():
             ab = (64 + 6 * 52) * m.density.numel()
         if name == 'dvgo_brick_scan':
             ab = 12 * ((args.world + 7) // 8) ** 3
+        if name == 'dvgo_march_scans':
+            ab = 12 * ((args.world + 7) // 8) ** 3 + 12 * args.rays
         kernels[name] = {'launches': cnt, 'avg_ms': per_ms, 'alg_bytes': ab,
                          'GBps': ab / per_ms / 1e6, 'frac': ab / per_ms / 1e6 / HBM_PEAK_GBS}
     march = {k: v for k, v in kernels.items() if k in ('dvgo_march_gather', 'dvgo_march_feat_bwd', 'dvgo_march_density',
                                                         'dvgo_march_density_bwd', 'dvgo_brick_accumulate')}
     dom = max(march, key=lambda k: march[k]['avg_ms']) if march else None
-    traffic = pmc_traffic(args.workload, args.world, args.rays)
+    traffic, traffic_source = pmc_traffic(args.workload, args.world, args.rays)
     for k in kernels:
         kernels[k]['traffic'] = traffic.get(k)
     roofline = None
     if dom:
         roofline = {'kernel': dom, 'bound': 'hbm', 'achieved': kernels[dom]['GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                    'frac': kernels[dom]['frac'], 'traffic': traffic.get(dom), 'alg_bytes_per_launch': kernels[dom]['alg_bytes'],
-                    'avg_launch_ms': kernels[dom]['avg_ms']}
+                    'frac': kernels[dom]['frac'], 'traffic': traffic.get(dom), 'traffic_source': traffic_source,
+                    'alg_bytes_per_launch': kernels[dom]['alg_bytes'], 'avg_launch_ms': kernels[dom]['avg_ms']}
     # the kernel BASELINE.json's north_star sets its 60 % target on (trilinear sample + composite, forward)
     ns = {k: {kk: kernels[k][kk] for kk in ('avg_ms', 'alg_bytes', 'GBps', 'frac', 'traffic')}
           for k in ('dvgo_march_gather', 'dvgo_march_composite') if k in kernels}

@@ -19,17 +19,19 @@
 //           parameters: the gradient then never exists in HBM.
 #include "common.h"
 
-// exclusive scan of the per-brick counts (single workgroup; nb is 8000 at 160^3, 32768 at 256^3)
-__global__ void __launch_bounds__(1024)
-brick_scan_kernel(const int32_t* __restrict__ cnt, int nb, int32_t* __restrict__ off, int32_t* __restrict__ cursor) {
+// exclusive scan of n int32 counts by ONE workgroup of 1024 threads: out[i] = sum of cnt[0..i), out[n] = total;
+// `copy` (optional) receives the same offsets (the fill cursors)
+template <typename OutT>
+__device__ __forceinline__ void block_scan_i32(const int32_t* __restrict__ cnt, int n, OutT* __restrict__ out,
+                                               int32_t* __restrict__ copy) {
   __shared__ int s_wave[16];
   __shared__ int s_carry;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid == 0) s_carry = 0;
   __syncthreads();
-  for (int base = 0; base < nb; base += 1024) {
+  for (int base = 0; base < n; base += 1024) {
     const int i = base + tid;
-    const int c = (i < nb) ? cnt[i] : 0;
+    const int c = (i < n) ? cnt[i] : 0;
     int inc = c;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -41,12 +43,27 @@ brick_scan_kernel(const int32_t* __restrict__ cnt, int nb, int32_t* __restrict__
     int wbase = s_carry;
     for (int w = 0; w < wave; ++w) wbase += s_wave[w];
     const int ex = wbase + inc - c;
-    if (i < nb) { off[i] = ex; cursor[i] = ex; }
+    if (i < n) { out[i] = (OutT)ex; if (copy) copy[i] = ex; }
     __syncthreads();
     if (tid == 1023) s_carry = ex + c;
     __syncthreads();
   }
-  if (tid == 0) off[nb] = s_carry;
+  if (tid == 0) out[n] = (OutT)s_carry;
+}
+
+__global__ void __launch_bounds__(1024)
+brick_scan_kernel(const int32_t* __restrict__ cnt, int nb, int32_t* __restrict__ off, int32_t* __restrict__ cursor) {
+  block_scan_i32<int32_t>(cnt, nb, off, cursor);
+}
+
+// the two scans between march_density and march_gather in one launch: workgroup 0 the kept-sample counts of the rays
+// (-> off3, int64 as the gather's output index), workgroup 1 the brick counts (-> offsets + fill cursors)
+__global__ void __launch_bounds__(1024)
+march_scans_kernel(const int32_t* __restrict__ n3, int n_rays, int64_t* __restrict__ off3,
+                   const int32_t* __restrict__ brick_cnt, int nb, int32_t* __restrict__ brick_off,
+                   int32_t* __restrict__ brick_cursor) {
+  if (blockIdx.x == 0) block_scan_i32<int64_t>(n3, n_rays, off3, nullptr);
+  else block_scan_i32<int32_t>(brick_cnt, nb, brick_off, brick_cursor);
 }
 
 struct BrickAdam {
@@ -332,6 +349,18 @@ int dvgo_brick_scan(const int32_t* brick_cnt, int n_bricks, int32_t* brick_off, 
   if (n_bricks < 0) return DVGO_EINVAL;
   if (!brick_cnt || !brick_off || !brick_cursor) return DVGO_EINVAL;
   brick_scan_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(brick_cnt, n_bricks, brick_off, brick_cursor);
+  DVGO_LAUNCH_CHECK();
+  return 0;
+}
+
+int dvgo_march_scans(const int32_t* n3, int64_t n_rays, int64_t* off3, const int32_t* brick_cnt, int n_bricks,
+                     int32_t* brick_off, int32_t* brick_cursor, void* stream) {
+  if (n_rays < 0 || n_bricks < 0 || n_rays >= ((int64_t)1 << 31)) return DVGO_EINVAL;
+  if (!off3 || (n_rays > 0 && !n3)) return DVGO_EINVAL;
+  const bool bricks = brick_cnt != nullptr;
+  if (bricks && (!brick_off || !brick_cursor)) return DVGO_EINVAL;
+  march_scans_kernel<<<bricks ? 2 : 1, 1024, 0, (hipStream_t)stream>>>(n3, (int)n_rays, off3, brick_cnt, n_bricks, brick_off,
+                                                                        brick_cursor);
   DVGO_LAUNCH_CHECK();
   return 0;
 }

@@ -150,7 +150,7 @@ march_density_kernel(const float* __restrict__ rays_start, const float* __restri
                      const int64_t* __restrict__ n_steps, const int64_t* __restrict__ cum,
                      int64_t rec_stride, int64_t n_rays, const uint8_t* __restrict__ mask,
                      const float* __restrict__ density, MarchParams P,
-                     dvgo_rec2_t* __restrict__ rec2, dvgo_rec3_t* __restrict__ rec3,
+                     dvgo_rec2_t* __restrict__ rec2,
                      int32_t* __restrict__ n2, int32_t* __restrict__ n3,
                      float* __restrict__ alphainv_last, int32_t* __restrict__ brick_cnt) {
   const int64_t ray = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -226,11 +226,6 @@ march_density_kernel(const float* __restrict__ rays_start, const float* __restri
       r.exp_d = e; r.alpha = a; r.T = T_before;
       rec2[cs0 + c2 + __popcll(m2 & lt)] = r;
     }
-    if (keep3) {
-      dvgo_rec3_t r;
-      r.step = step; r.weight = w; r.alpha = a; r.j2 = c2 + __popcll(m2 & lt);
-      rec3[cs0 + c3 + __popcll(m3 & lt)] = r;
-    }
     c2 += __popcll(m2);
     c3 += __popcll(m3);
     if (brick_cnt != nullptr) brick_emit<false>(valid2, t.i0, t.j0, t.k0, P.X, P.Y, P.Z, lane, brick_cnt, nullptr, make_int4(0, 0, 0, 0));
@@ -278,80 +273,102 @@ march_hit_kernel(const float* __restrict__ rays_start, const float* __restrict__
 }
 
 // ----------------------------------------------------------------------------------
-// march_gather: flat over M3.  C4 = C/4 channel vectors when the grid is channels-last.
+// march_gather: one wavefront per ray over the ray's rec2 records (lanes = 64 consecutive records).  The records
+// flagged "kept" by march_density are compacted with a ballot to their final position off3[ray] + rank -- the
+// reference's (ray, step) order after its 4th boolean compaction (lib/dvgo.py:488-509) -- and each kept lane
+// interpolates its feature row (8 corners x 16-byte channel vectors when the grid is channels-last) and writes the
+// ids / weight / alpha of its sample.  weight = T * alpha is the product march_density formed for its filter, from
+// the same two floats, so no second record array travels between the two kernels.
 // ----------------------------------------------------------------------------------
 template <int CVEC, int CS = 0>   // CVEC > 0: channels-last, C == 4*CVEC, 16-B aligned; CS > 0: channels-last, C == CS, dword
 __global__ void __launch_bounds__(DVGO_BLOCK)   // loads (rows of 3 / 9 floats: coarse stage, LLFF); both 0: generic strides
-march_gather_kernel(const dvgo_rec3_t* __restrict__ rec3, const int64_t* __restrict__ n_steps,
+march_gather_kernel(const dvgo_rec2_t* __restrict__ rec2, const int32_t* __restrict__ n2, const int64_t* __restrict__ n_steps,
                     const int64_t* __restrict__ cum, int64_t rec_stride, const int64_t* __restrict__ off3,
-                    int64_t n_rays, int64_t M3, const float* __restrict__ rays_start, const float* __restrict__ rays_dir,
+                    int64_t n_rays, const float* __restrict__ rays_start, const float* __restrict__ rays_dir,
                     MarchParams P, const float* __restrict__ k0, int C, int64_t sC, int64_t sX,
                     int64_t sY, int64_t sZ, int64_t* __restrict__ ray_id, int64_t* __restrict__ step_id,
                     float* __restrict__ weights, float* __restrict__ alpha, float* __restrict__ feat) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= M3) return;
-  const int64_t r = dvgo_upper_bound(off3 + 1, n_rays, i);   // off3[r] <= i < off3[r+1]
-  const int64_t k = i - off3[r];
-  const dvgo_rec3_t rec = rec3[rec_base(cum, n_steps, rec_stride, r) + k];
-  ray_id[i] = r;
-  step_id[i] = rec.step;
-  weights[i] = rec.weight;
-  alpha[i] = rec.alpha;
-  float px, py, pz;
-  march_pos(rays_start, rays_dir, r, P.stepdist, rec.step, px, py, pz);
-  const TriSetup t = dvgo_tri_setup(px, py, pz, P.mnx, P.mny, P.mnz, P.mxx, P.mxy, P.mxz, P.X, P.Y, P.Z);
-  float w[8];
-  int64_t off[8];
-  bool ok[8];
-#pragma unroll
-  for (int n = 0; n < 8; ++n) {
-    w[n] = dvgo_tri_weight(t, n);
-    ok[n] = dvgo_tri_inb(t, n, P.X, P.Y, P.Z);
-    off[n] = (int64_t)(t.i0 + ((n >> 2) & 1)) * sX + (int64_t)(t.j0 + ((n >> 1) & 1)) * sY +
-             (int64_t)(t.k0 + (n & 1)) * sZ;
-  }
-  if (CVEC > 0) {
-    float4 acc[CVEC > 0 ? CVEC : 1];
-#pragma unroll
-    for (int c = 0; c < CVEC; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (r >= n_rays) return;
+  const int c2 = __builtin_amdgcn_readfirstlane(n2[r]);
+  if (c2 == 0) return;
+  const int64_t cs0 = rec_base(cum, n_steps, rec_stride, r);
+  int64_t out = off3[r];
+  const float sx = rays_start[3 * r], sy = rays_start[3 * r + 1], sz = rays_start[3 * r + 2];
+  const float dx = rays_dir[3 * r], dy = rays_dir[3 * r + 1], dz = rays_dir[3 * r + 2];
+  const unsigned long long lt = lanemask_lt(lane);
+  for (int lo = 0; lo < c2; lo += 64) {
+    const int j = lo + lane;
+    dvgo_rec2_t rec;
+    rec.step = 0; rec.exp_d = 0.f; rec.alpha = 0.f; rec.T = 0.f;
+    if (j < c2) rec = rec2[cs0 + j];
+    const bool kept = (j < c2) && (rec.step < 0);
+    const unsigned long long m = __ballot(kept);
+    const int64_t i = out + __popcll(m & lt);
+    out += __popcll(m);
+    if (!kept) continue;
+    const int step = rec.step & 0x7fffffff;
+    ray_id[i] = r;
+    step_id[i] = step;
+    weights[i] = rec.T * rec.alpha;
+    alpha[i] = rec.alpha;
+    const float dist = march_dist(P.stepdist, step);
+    const float px = fmaf(dx, dist, sx), py = fmaf(dy, dist, sy), pz = fmaf(dz, dist, sz);
+    const TriSetup t = dvgo_tri_setup(px, py, pz, P.mnx, P.mny, P.mnz, P.mxx, P.mxy, P.mxz, P.X, P.Y, P.Z);
+    float w[8];
+    int64_t off[8];
+    bool ok[8];
 #pragma unroll
     for (int n = 0; n < 8; ++n) {
-      if (ok[n]) {
-        const float4* p = reinterpret_cast<const float4*>(k0 + off[n]);
+      w[n] = dvgo_tri_weight(t, n);
+      ok[n] = dvgo_tri_inb(t, n, P.X, P.Y, P.Z);
+      off[n] = (int64_t)(t.i0 + ((n >> 2) & 1)) * sX + (int64_t)(t.j0 + ((n >> 1) & 1)) * sY +
+               (int64_t)(t.k0 + (n & 1)) * sZ;
+    }
+    if (CVEC > 0) {
+      float4 acc[CVEC > 0 ? CVEC : 1];
 #pragma unroll
-        for (int c = 0; c < CVEC; ++c) {
-          const float4 v = p[c];
-          acc[c].x = fmaf(v.x, w[n], acc[c].x);
-          acc[c].y = fmaf(v.y, w[n], acc[c].y);
-          acc[c].z = fmaf(v.z, w[n], acc[c].z);
-          acc[c].w = fmaf(v.w, w[n], acc[c].w);
+      for (int c = 0; c < CVEC; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int n = 0; n < 8; ++n) {
+        if (ok[n]) {
+          const float4* p = reinterpret_cast<const float4*>(k0 + off[n]);
+#pragma unroll
+          for (int c = 0; c < CVEC; ++c) {
+            const float4 v = p[c];
+            acc[c].x = fmaf(v.x, w[n], acc[c].x);
+            acc[c].y = fmaf(v.y, w[n], acc[c].y);
+            acc[c].z = fmaf(v.z, w[n], acc[c].z);
+            acc[c].w = fmaf(v.w, w[n], acc[c].w);
+          }
         }
       }
-    }
-    float4* o = reinterpret_cast<float4*>(feat + i * (int64_t)(4 * CVEC));
+      float4* o = reinterpret_cast<float4*>(feat + i * (int64_t)(4 * CVEC));
 #pragma unroll
-    for (int c = 0; c < CVEC; ++c) o[c] = acc[c];
-  } else if (CS > 0) {
-    float acc[CS > 0 ? CS : 1];
+      for (int c = 0; c < CVEC; ++c) o[c] = acc[c];
+    } else if (CS > 0) {
+      float acc[CS > 0 ? CS : 1];
 #pragma unroll
-    for (int c = 0; c < CS; ++c) acc[c] = 0.f;
+      for (int c = 0; c < CS; ++c) acc[c] = 0.f;
 #pragma unroll
-    for (int n = 0; n < 8; ++n) {
-      if (ok[n]) {
-        const float* p = k0 + off[n];
+      for (int n = 0; n < 8; ++n) {
+        if (ok[n]) {
+          const float* p = k0 + off[n];
 #pragma unroll
-        for (int c = 0; c < CS; ++c) acc[c] = fmaf(p[c], w[n], acc[c]);
+          for (int c = 0; c < CS; ++c) acc[c] = fmaf(p[c], w[n], acc[c]);
+        }
       }
-    }
 #pragma unroll
-    for (int c = 0; c < CS; ++c) feat[i * CS + c] = acc[c];
-  } else {
-    for (int c = 0; c < C; ++c) {
-      float acc = 0.f;
+      for (int c = 0; c < CS; ++c) feat[i * CS + c] = acc[c];
+    } else {
+      for (int c = 0; c < C; ++c) {
+        float acc = 0.f;
 #pragma unroll
-      for (int n = 0; n < 8; ++n)
-        if (ok[n]) acc = fmaf(k0[c * sC + off[n]], w[n], acc);
-      feat[i * C + c] = acc;
+        for (int n = 0; n < 8; ++n)
+          if (ok[n]) acc = fmaf(k0[c * sC + off[n]], w[n], acc);
+        feat[i * C + c] = acc;
+      }
     }
   }
 }
@@ -758,12 +775,12 @@ int dvgo_march_density(const float* rays_start, const float* rays_dir, const int
                        const float* xyz_max, float stepdist, const uint8_t* mask, int mX, int mY, int mZ,
                        const float* xyz2ijk_scale, const float* xyz2ijk_shift, const float* density,
                        int X, int Y, int Z, float act_shift, float interval, float fast_color_thres,
-                       dvgo_rec2_t* rec2, dvgo_rec3_t* rec3, int32_t* n2, int32_t* n3,
+                       dvgo_rec2_t* rec2, int32_t* n2, int32_t* n3,
                        float* alphainv_last, int32_t* brick_cnt, void* stream) {
   if (n_rays < 0 || X <= 0 || Y <= 0 || Z <= 0) return DVGO_EINVAL;
   if (n_rays == 0) return 0;
   if (!rays_start || !rays_dir || !n_steps || !xyz_min || !xyz_max || !density ||
-      !rec2 || !rec3 || !n2 || !n3 || !alphainv_last)
+      !rec2 || !n2 || !n3 || !alphainv_last)
     return DVGO_EINVAL;
   if (!n_steps_cumsum && rec_stride <= 0) return DVGO_EINVAL;
   if (mask && (!xyz2ijk_scale || !xyz2ijk_shift || mX <= 0 || mY <= 0 || mZ <= 0)) return DVGO_EINVAL;
@@ -771,7 +788,7 @@ int dvgo_march_density(const float* rays_start, const float* rays_dir, const int
   const MarchParams P = make_params(xyz_min, xyz_max, stepdist, xyz2ijk_scale, xyz2ijk_shift, mX, mY, mZ,
                                     X, Y, Z, act_shift, interval, fast_color_thres);
   march_density_kernel<<<dvgo_blocks(n_rays * 64, DVGO_BLOCK), DVGO_BLOCK, 0, (hipStream_t)stream>>>(
-      rays_start, rays_dir, n_steps, n_steps_cumsum, rec_stride, n_rays, mask, density, P, rec2, rec3, n2, n3,
+      rays_start, rays_dir, n_steps, n_steps_cumsum, rec_stride, n_rays, mask, density, P, rec2, n2, n3,
       alphainv_last, brick_cnt);
   DVGO_LAUNCH_CHECK();
   return 0;
@@ -793,38 +810,34 @@ int dvgo_march_hit(const float* rays_start, const float* rays_dir, const int64_t
   return 0;
 }
 
-int dvgo_march_gather(const dvgo_rec3_t* rec3, const int64_t* n_steps, const int64_t* n_steps_cumsum,
+int dvgo_march_gather(const dvgo_rec2_t* rec2, const int32_t* n2, const int64_t* n_steps, const int64_t* n_steps_cumsum,
                       int64_t rec_stride, const int64_t* off3, int64_t n_rays, int64_t M3, const float* rays_start,
                       const float* rays_dir, float stepdist, const float* xyz_min, const float* xyz_max,
                       const float* k0, int C, int X, int Y, int Z, int64_t sC, int64_t sX, int64_t sY,
                       int64_t sZ, int64_t* ray_id, int64_t* step_id, float* weights, float* alpha,
                       float* feat, void* stream) {
   if (n_rays < 0 || M3 < 0 || C < 0 || X <= 0 || Y <= 0 || Z <= 0) return DVGO_EINVAL;
-  if (M3 == 0) return 0;
-  if (!rec3 || !n_steps || !off3 || !rays_start || !rays_dir || !xyz_min || !xyz_max ||
+  if (M3 == 0 || n_rays == 0) return 0;
+  if (!rec2 || !n2 || !n_steps || !off3 || !rays_start || !rays_dir || !xyz_min || !xyz_max ||
       !ray_id || !step_id || !weights || !alpha || (C > 0 && (!k0 || !feat)))
     return DVGO_EINVAL;
   if (!n_steps_cumsum && rec_stride <= 0) return DVGO_EINVAL;
-  if (!dvgo_fits(M3)) return DVGO_ERANGE;
+  if (!dvgo_fits(n_rays * 64)) return DVGO_ERANGE;
   const MarchParams P = make_params(xyz_min, xyz_max, stepdist, nullptr, nullptr, 0, 0, 0, X, Y, Z, 0.f, 0.f, 0.f);
   hipStream_t s = (hipStream_t)stream;
-  const int blocks = dvgo_blocks(M3, DVGO_BLOCK);
+  const int blocks = dvgo_blocks(n_rays * 64, DVGO_BLOCK);
   const bool vec = (sC == 1) && (C % 4 == 0) && (sX % 4 == 0) && (sY % 4 == 0) && (sZ % 4 == 0) &&
                    ((((uintptr_t)k0) & 15) == 0) && ((((uintptr_t)feat) & 15) == 0);
-#define DVGO_GATHER(CV)                                                                              \
-  march_gather_kernel<CV><<<blocks, DVGO_BLOCK, 0, s>>>(rec3, n_steps, n_steps_cumsum, rec_stride, off3, \
-      n_rays, M3, rays_start, rays_dir, P, k0, C, sC, sX, sY, sZ, ray_id, step_id, weights, alpha, feat)
-  if (vec && C == 12) DVGO_GATHER(3);
-  else if (vec && C == 4) DVGO_GATHER(1);
-  else if (vec && C == 8) DVGO_GATHER(2);
-  else if (vec && C == 16) DVGO_GATHER(4);
-  else if (sC == 1 && C == 9)
-    march_gather_kernel<0, 9><<<blocks, DVGO_BLOCK, 0, s>>>(rec3, n_steps, n_steps_cumsum, rec_stride, off3, n_rays, M3, rays_start,
-        rays_dir, P, k0, C, sC, sX, sY, sZ, ray_id, step_id, weights, alpha, feat);
-  else if (sC == 1 && C == 3)
-    march_gather_kernel<0, 3><<<blocks, DVGO_BLOCK, 0, s>>>(rec3, n_steps, n_steps_cumsum, rec_stride, off3, n_rays, M3, rays_start,
-        rays_dir, P, k0, C, sC, sX, sY, sZ, ray_id, step_id, weights, alpha, feat);
-  else DVGO_GATHER(0);
+#define DVGO_GATHER(CV, CSS)                                                                                      \
+  march_gather_kernel<CV, CSS><<<blocks, DVGO_BLOCK, 0, s>>>(rec2, n2, n_steps, n_steps_cumsum, rec_stride, off3, \
+      n_rays, rays_start, rays_dir, P, k0, C, sC, sX, sY, sZ, ray_id, step_id, weights, alpha, feat)
+  if (vec && C == 12) DVGO_GATHER(3, 0);
+  else if (vec && C == 4) DVGO_GATHER(1, 0);
+  else if (vec && C == 8) DVGO_GATHER(2, 0);
+  else if (vec && C == 16) DVGO_GATHER(4, 0);
+  else if (sC == 1 && C == 9) DVGO_GATHER(0, 9);
+  else if (sC == 1 && C == 3) DVGO_GATHER(0, 3);
+  else DVGO_GATHER(0, 0);
 #undef DVGO_GATHER
   DVGO_LAUNCH_CHECK();
   return 0;

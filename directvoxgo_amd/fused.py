@@ -22,7 +22,7 @@ from . import _lib as L
 from ._lib import _flt, _i64, _int, check_f32, check_input, f3, ptr, stream_of
 from .ops import _grid_geom
 
-# scratch budget for fixed-stride records (2 x 16 B per potential sample)
+# scratch budget for fixed-stride records (16 B per potential sample)
 _MAX_STRIDE_SCRATCH_BYTES = 4 << 30
 
 
@@ -56,7 +56,7 @@ def _rec_stride(cfg, n_rays):
     if not math.isfinite(span) or span < 0:
         return 0
     stride = int(math.ceil(span)) + 2
-    if stride * n_rays * 32 > _MAX_STRIDE_SCRATCH_BYTES:
+    if stride * n_rays * 16 > _MAX_STRIDE_SCRATCH_BYTES:
         return 0
     return stride
 
@@ -149,7 +149,6 @@ class _FusedMarch(torch.autograd.Function):
             else:
                 cap = stride * N
             rec2 = torch.empty((max(cap, 1), 4), dtype=torch.float32, device=dev)
-            rec3 = torch.empty((max(cap, 1), 4), dtype=torch.float32, device=dev)
             # training: count, per 8^3 brick, the samples the backward will list for it (csrc/brick.hip)
             bricks = (BRICK_SCATTER and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and C in BRICK_CHANNELS
                       and tuple(density.shape[2:]) == (X, Y, Z) and (sC, sZ, sY, sX) == (1, C, Z * C, Y * Z * C)
@@ -165,12 +164,17 @@ class _FusedMarch(torch.autograd.Function):
             L.call('dvgo_march_density', ptr(start), ptr(dirs), ptr(n_steps), ptr(cum), _i64(stride), _i64(N),
                    cfg.xyz_min_h, cfg.xyz_max_h, _flt(cfg.stepdist), ptr(mask), _int(mshape[0]), _int(mshape[1]),
                    _int(mshape[2]), cfg.scale_h, cfg.shift_h, ptr(density), _int(X), _int(Y), _int(Z),
-                   _flt(cfg.act_shift), _flt(cfg.interval), _flt(cfg.thres), ptr(rec2), ptr(rec3), ptr(n2), ptr(n3),
+                   _flt(cfg.act_shift), _flt(cfg.interval), _flt(cfg.thres), ptr(rec2), ptr(n2), ptr(n3),
                    ptr(last), ptr(brick_cnt), st)
-            L.call('dvgo_exclusive_scan_i32', ptr(n3), _i64(N), ptr(off3), st)
             n_entries = 0
+            if N <= 16384:              # both scans in one launch (one workgroup each)
+                L.call('dvgo_march_scans', ptr(n3), _i64(N), ptr(off3), ptr(brick_cnt), _int(nb if bricks else 0),
+                       ptr(brick_off), ptr(brick_cur), st)
+            else:                       # render-sized batches: the multi-workgroup scan
+                L.call('dvgo_exclusive_scan_i32', ptr(n3), _i64(N), ptr(off3), st)
+                if bricks:
+                    L.call('dvgo_brick_scan', ptr(brick_cnt), _int(nb), ptr(brick_off), ptr(brick_cur), st)
             if bricks:
-                L.call('dvgo_brick_scan', ptr(brick_cnt), _int(nb), ptr(brick_off), ptr(brick_cur), st)
                 M3, n_entries = torch.stack((off3[-1], brick_off[-1].long())).tolist()   # the one host sync
             else:
                 M3 = int(off3[-1].item())                      # the one host sync of the fused forward
@@ -179,11 +183,10 @@ class _FusedMarch(torch.autograd.Function):
             weights = torch.empty(M3, dtype=torch.float32, device=dev)
             alpha = torch.empty(M3, dtype=torch.float32, device=dev)
             feat = torch.empty((M3, C), dtype=torch.float32, device=dev)
-            L.call('dvgo_march_gather', ptr(rec3), ptr(n_steps), ptr(cum), _i64(stride), ptr(off3), _i64(N), _i64(M3),
+            L.call('dvgo_march_gather', ptr(rec2), ptr(n2), ptr(n_steps), ptr(cum), _i64(stride), ptr(off3), _i64(N), _i64(M3),
                    ptr(start), ptr(dirs), _flt(cfg.stepdist), cfg.xyz_min_h, cfg.xyz_max_h, ptr(k0), _int(C),
                    _int(X), _int(Y), _int(Z), _i64(sC), _i64(sX), _i64(sY), _i64(sZ), ptr(ray_id), ptr(step_id),
                    ptr(weights), ptr(alpha), ptr(feat), st)
-        del rec3
         ctx.cfg = cfg
         ctx.geom = (X, Y, Z, C, sC, sX, sY, sZ, stride, N)
         ctx.bricks = (brick_off, brick_cur, n_entries) if bricks else None

@@ -183,12 +183,10 @@ int dvgo_segment_sum(const float* src, const int64_t* index, int64_t M, int C,
  *                                compositing (post alpha filter, up to and including the early-stop
  *                                sample); step has bit 31 set when the sample also passed the
  *                                weight filter
- *     rec3[base+k] (k < n3[r]) : {step, weight, alpha, j2} of the k-th sample that survived both
- *                                filters (the reference's final sample set)
- *   and n2[r], n3[r], alphainv_last[r].  mask may be NULL (no occupancy skipping).
+ *   and n2[r] (records of the ray), n3[r] (how many of them passed the weight filter: the reference's final
+ *   sample set), alphainv_last[r].  mask may be NULL (no occupancy skipping).
  * --------------------------------------------------------------------------------- */
 typedef struct { int32_t step; float exp_d; float alpha; float T; } dvgo_rec2_t;     /* 16 B */
-typedef struct { int32_t step; float weight; float alpha; int32_t j2; } dvgo_rec3_t; /* 16 B */
 
 int dvgo_march_density(const float* rays_start, const float* rays_dir,
                        const int64_t* n_steps, const int64_t* n_steps_cumsum, int64_t rec_stride,
@@ -198,7 +196,7 @@ int dvgo_march_density(const float* rays_start, const float* rays_dir,
                        const float* xyz2ijk_scale, const float* xyz2ijk_shift,
                        const float* density, int X, int Y, int Z,            /* [X,Y,Z] contiguous */
                        float act_shift, float interval, float fast_color_thres,
-                       dvgo_rec2_t* rec2, dvgo_rec3_t* rec3,
+                       dvgo_rec2_t* rec2,
                        int32_t* n2, int32_t* n3, float* alphainv_last,
                        int32_t* brick_cnt /* NULL, or [dvgo_n_bricks(X,Y,Z)] zero-initialised counters: the samples
                                              that entered compositing are counted per brick for the backward's
@@ -215,10 +213,11 @@ int dvgo_march_hit(const float* rays_start, const float* rays_dir, const int64_t
 /* exclusive scan of int32 counts -> int64 offsets [n+1] (offsets[n] = total) */
 int dvgo_exclusive_scan_i32(const int32_t* counts, int64_t n, int64_t* offsets, void* stream);
 
-/* dvgo_march_gather: flat over the M3 = off3[N] surviving samples (ray-major, the reference's
- *   order).  Writes ray_id, step_id [M3] int64; weights, alpha [M3]; k0 features [M3,C]
- *   trilinearly interpolated from the feature grid (element strides as dvgo_grid_sample_fwd). */
-int dvgo_march_gather(const dvgo_rec3_t* rec3, const int64_t* n_steps, const int64_t* n_steps_cumsum,
+/* dvgo_march_gather: one wavefront per ray over its rec2 records; the records flagged as kept are compacted to
+ *   [off3[r], off3[r+1]) (ray-major, the reference's order; off3 = exclusive scan of n3, M3 = off3[N]).  Writes
+ *   ray_id, step_id [M3] int64; weights (= T * alpha), alpha [M3]; k0 features [M3,C] trilinearly interpolated from
+ *   the feature grid (element strides as dvgo_grid_sample_fwd). */
+int dvgo_march_gather(const dvgo_rec2_t* rec2, const int32_t* n2, const int64_t* n_steps, const int64_t* n_steps_cumsum,
                       int64_t rec_stride, const int64_t* off3, int64_t n_rays, int64_t M3,
                       const float* rays_start, const float* rays_dir, float stepdist,
                       const float* xyz_min, const float* xyz_max,
@@ -300,6 +299,10 @@ int dvgo_march_density_bwd(const dvgo_rec2_t* rec2, const int32_t* n2, const int
  * --------------------------------------------------------------------------------- */
 int dvgo_n_bricks(int X, int Y, int Z);
 int dvgo_brick_scan(const int32_t* brick_cnt, int n_bricks, int32_t* brick_off, int32_t* brick_cursor, void* stream);
+/* dvgo_exclusive_scan_i32(n3 -> off3) and dvgo_brick_scan in ONE launch (two workgroups; brick_cnt may be NULL: only the
+ * first).  One workgroup per scan: meant for training batches (n_rays up to a few 10^4). */
+int dvgo_march_scans(const int32_t* n3, int64_t n_rays, int64_t* off3, const int32_t* brick_cnt, int n_bricks,
+                     int32_t* brick_off, int32_t* brick_cursor, void* stream);
 int dvgo_brick_accumulate(const int32_t* brick_off, const void* recs, const float* rays_start, const float* rays_dir,
                           float stepdist, const float* xyz_min, const float* xyz_max, const float* grad_feat,
                           int C, int X, int Y, int Z, float* grad_k0, float* grad_density,

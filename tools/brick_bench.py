@@ -21,7 +21,7 @@ ap.add_argument('--rays', type=int, default=8192)
 ap.add_argument('--workload', default='roofline')
 args = ap.parse_args()
 
-NAMES = ['dvgo_march_density', 'dvgo_brick_scan', 'dvgo_march_density_bwd', 'dvgo_brick_accumulate', 'dvgo_march_feat_bwd',
+NAMES = ['dvgo_sample_pts_prepare', 'dvgo_march_density', 'dvgo_march_scans', 'dvgo_exclusive_scan_i32', 'dvgo_march_gather', 'dvgo_march_composite', 'dvgo_march_composite_bwd', 'dvgo_shade_fwd', 'dvgo_shade_bwd', 'dvgo_shade_wgrad', 'dvgo_brick_scan', 'dvgo_march_density_bwd', 'dvgo_brick_accumulate', 'dvgo_march_feat_bwd',
          'dvgo_grid_grad_split', 'dvgo_adam_rows', 'dvgo_adam_upd']
 
 

@@ -2,7 +2,7 @@
 
 On the GPU box (one gpurun call; counters in their own passes, as MI355X_MICROARCH.md prescribes):
     R=$GRAFT_REPO_ROOT; cd /tmp && export TMPDIR=/tmp
-    rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_kt    -- python $R/bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-secondary
+    rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_kt    -- python $R/bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-secondary --single-stream
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_fetch -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-secondary
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_write -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-secondary
     rocprofv3 --pmc TCC_EA0_ATOMIC_sum --output-format csv -d $R/gpurun_out/prof_atom -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-secondary   (optional)
@@ -23,7 +23,9 @@ ENTRY = [   # kernel-name fragment -> C-ABI entry point (first match wins)
     ('grid_grad_split_kernel', 'dvgo_grid_grad_split'), ('shade_fwd_kernel', 'dvgo_shade_fwd'),
     ('shade_bwd_kernel', 'dvgo_shade_bwd'), ('shade_wgrad_kernel', 'dvgo_shade_wgrad'), ('adam_rows_kernel', 'dvgo_adam_rows'),
     ('adam_kernel', 'dvgo_adam_upd'),
-    ('ray_setup_kernel', 'dvgo_sample_pts_prepare'), ('scan_kernel<int', 'dvgo_exclusive_scan_i32'),
+    ('ray_setup_kernel', 'dvgo_sample_pts_prepare'), ('march_scans_kernel', 'dvgo_march_scans'),
+    ('brick_scan_kernel', 'dvgo_brick_scan'), ('brick_accumulate_kernel', 'dvgo_brick_accumulate'),
+    ('scan_kernel<int', 'dvgo_exclusive_scan_i32'),
 ]
 
 
@@ -48,7 +50,7 @@ def kernel_stats(src, dst, note):
         f.write(open(path).read())
     total = sum(float(r['TotalDurationNs']) for r in rows) / 1e6
     with open(os.path.join(dst, 'bench_summary.md'), 'w') as f:
-        f.write('# rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-secondary\n\n')
+        f.write('# rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-secondary --single-stream\n\n')
         f.write(f'{note} Total kernel time {total:.1f} ms.\n\n| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n')
         for r in rows[:30]:
             f.write(f"| `{r['Name'][:72]}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.3f} | "
