@@ -34,6 +34,8 @@ def lib():
         v = _lib.dvgo_abi_version()
         if v != ABI_VERSION:
             raise RuntimeError(f'libdvgo_hip.so ABI {v} != expected {ABI_VERSION}: rebuild')
+        if os.environ.get('DVGO_SHADE_VARIANT'):          # A/B runs (tools/): colour-head kernel variant bits
+            _lib.dvgo_shade_variant(int(os.environ['DVGO_SHADE_VARIANT']))
     return _lib
 
 

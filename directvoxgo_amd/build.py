@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 SO = os.path.join(CSRC, 'libdvgo_hip.so')
-SOURCES = ['sampling.hip', 'pointwise.hip', 'composite.hip', 'grid_sample.hip', 'march.hip', 'optim.hip', 'shade.hip', 'loss.hip', 'brick.hip', 'maintain.hip']
+SOURCES = ['sampling.hip', 'pointwise.hip', 'composite.hip', 'grid_sample.hip', 'march.hip', 'optim.hip', 'shade.hip', 'shade_x3.hip', 'loss.hip', 'brick.hip', 'maintain.hip']
 HEADERS = ['common.h', os.path.join('..', '..', 'include', 'dvgo_hip.h')]
 
 # -ffp-contract=off : a*b+c is fused only where the source says fmaf(), so that index and

@@ -25,6 +25,17 @@
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 static int g_shade_experiment = 0;   // timing experiments only (tools/): bit 0 = skip G1/G2 stores in shade_bwd
+// kernel variants (dvgo_shade_variant): bit 0 = forward, bit 1 = data gradients on the bf16 matrix cores with a 3-way
+// operand split (shade_x3.hip)
+static int g_shade_variant = 3;
+extern "C" int dvgo_shade_bwd_x3(const float* g_rgb, const float* rgb, const uint64_t* masks, int64_t M,
+                                 const float* W1, const float* W2, const float* W3, int width, int d_in, int C, int diffuse,
+                                 float* g_feat, float* G1, float* gz, void* scratch, void* stream);
+
+extern "C" int dvgo_shade_fwd_x3(const float* feat, int C, const float* emb, int E, const int64_t* ray_id, int64_t M,
+                                 const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
+                                 const float* b3, int width, int d_in, int diffuse, float* rgb, float* H1, float* H2,
+                                 uint64_t* masks, void* scratch, int experiment, void* stream);
 
 // Saved activations / gradients are plain row-major [M, features]: in the accumulator layout a lane owns
 // 4 consecutive features per register quad, i.e. one 16-byte piece of its row.
@@ -574,7 +585,7 @@ extern "C" {
 int dvgo_shade_fwd(const float* feat, int C, const float* emb, int E, const int64_t* ray_id, int64_t M,
                    const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
                    const float* b3, int width, int d_in, int diffuse, float* rgb, float* H1, float* H2,
-                   uint64_t* masks, void* stream) {
+                   uint64_t* masks, void* scratch, void* stream) {
   if (M < 0 || C <= 0 || E < 0) return DVGO_EINVAL;
   if (M == 0) return 0;
   if (!feat || !emb || !ray_id || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !rgb) return DVGO_EINVAL;
@@ -583,6 +594,9 @@ int dvgo_shade_fwd(const float* feat, int C, const float* emb, int E, const int6
   const int n_view = C - c_view0;
   if (n_view < 0 || d_in != n_view + E) return DVGO_EINVAL;
   if ((width != 128 && width != 64) || d_in > 40) return DVGO_ERANGE;   // outside the instantiated set: caller falls back
+  if ((g_shade_variant & 1) && scratch != nullptr)
+    return dvgo_shade_fwd_x3(feat, C, emb, E, ray_id, M, W1, b1, W2, b2, W3, b3, width, d_in, diffuse, rgb, H1, H2, masks,
+                             scratch, g_shade_experiment, stream);
   hipStream_t s = (hipStream_t)stream;
   const int64_t n_tiles = (M + 31) / 32;
   const int64_t cap = width == 128 ? 256 : 512;          // width 128: one workgroup per CU (LDS); width 64: two
@@ -606,15 +620,19 @@ int dvgo_shade_fwd(const float* feat, int C, const float* emb, int E, const int6
 
 int dvgo_shade_experiment(int flags) { g_shade_experiment = flags; return 0; }
 
+int dvgo_shade_variant(int flags) { const int old = g_shade_variant; if (flags >= 0) g_shade_variant = flags; return old; }
+
 int dvgo_shade_bwd(const float* g_rgb, const float* rgb, const uint64_t* masks, int64_t M,
                    const float* W1, const float* W2, const float* W3, int width, int d_in, int C, int diffuse,
-                   float* g_feat, float* G1, float* gz, void* stream) {
+                   float* g_feat, float* G1, float* gz, void* scratch, void* stream) {
   if (M < 0 || C <= 0) return DVGO_EINVAL;
   if (M == 0) return 0;
   if (!g_rgb || !rgb || !masks || !W1 || !W2 || !W3 || !g_feat || !G1 || !gz) return DVGO_EINVAL;
   const int c_view0 = diffuse ? 3 : 0;
   const int n_view = C - c_view0;
   if ((width != 128 && width != 64) || n_view < 0 || n_view > 32 || d_in < n_view) return DVGO_ERANGE;
+  if ((g_shade_variant & 2) && scratch != nullptr)
+    return dvgo_shade_bwd_x3(g_rgb, rgb, masks, M, W1, W2, W3, width, d_in, C, diffuse, g_feat, G1, gz, scratch, stream);
   hipStream_t s = (hipStream_t)stream;
   const int64_t n_tiles = (M + 31) / 32;
   const int64_t cap = width == 128 ? 256 : 512;

@@ -1,0 +1,502 @@
+// Colour head on the bf16 matrix cores with fp32 results: every fp32 operand is split EXACTLY into three bf16 pieces,
+//     x = x0 + x1 + x2,   x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1)        (8 + 8 + 8 mantissa bits)
+// and a product is taken as the six partial products of order < 2^-24,
+//     x w  ~  x0 w0 + x0 w1 + x1 w0 + x0 w2 + x1 w1 + x2 w0        (dropped: x1 w2 + x2 w1 + x2 w2 <= 2^-23 |x w|)
+// each an exact bf16 x bf16 product accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  The rounding of the result is
+// that of an fp32 dot product (the dropped terms are below the fp32 rounding of the sum), but six bf16 MFMAs cover a
+// 16-deep k-step in 6 x 32 cycles where v_mfma_f32_32x32x2_f32 needs 8 x 64: 2.7x fewer matrix-pipe cycles
+// (tools/micro/bf16x3_loop.hip: the 128 x 128 layer sustains 260-270 TFLOP/s fp32-equivalent against 122 for the f32
+// MFMA loop of shade.hip).  The reference runs this MLP in fp32 (lib/dvgo.py:123-131,516-541); the tests that hold the
+// f32-MFMA kernels against the torch modules (rtol 1e-5 values, 2e-4 gradients) hold these kernels unchanged.
+//
+// Structure = shade.hip's: every layer is computed transposed (weights = A operand, activations = B operand), so a
+// 32 x 32 result tile has the sample on the lane and 16 output features in the registers; registers 8s .. 8s+7 of a
+// tile, converted, ARE the B fragment of k-step s of the next layer (cdna_hip_programming.md "An accumulator tile as
+// the next MFMA's operand"), with the weights stored in LDS pre-split and pre-permuted to that k order.  Activations
+// never leave registers; the splits cost ~11 VALU instructions per pair of values, issued between the MFMAs.
+#include "common.h"
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+
+#define X3_THREADS 512                 // 8 wavefronts: two per SIMD (<= 256 registers), one workgroup per CU (LDS)
+#define X3_WAVES (X3_THREADS / 64)
+#define X3_STAGE_ROWS 16
+#define X3_STAGE_STRIDE 36
+
+__device__ __forceinline__ int x3_acc_feature(int t, int r, int h) { return 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+__device__ __forceinline__ unsigned int x3_pack(float a, float b) {          // two fp32 -> two bf16 (RNE), a in the low half
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+  typedef __attribute__((ext_vector_type(2))) float f32x2;
+  f32x2 v; v[0] = a; v[1] = b;
+  return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2));
+}
+
+// 8 fp32 -> the three bf16 fragments (element j of the fragment = v[j])
+__device__ __forceinline__ void x3_split8(const float (&v)[8], u32x4& s0, u32x4& s1, u32x4& s2) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const float a = v[2 * p], b = v[2 * p + 1];
+    const unsigned int h = x3_pack(a, b);
+    const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
+    const unsigned int m = x3_pack(ra, rb);
+    const float qa = ra - __uint_as_float(m << 16), qb = rb - __uint_as_float(m & 0xffff0000u);
+    s0[p] = h; s1[p] = m; s2[p] = x3_pack(qa, qb);
+  }
+}
+
+__device__ __forceinline__ void x3_split1(float v, unsigned short& s0, unsigned short& s1, unsigned short& s2) {
+  const unsigned int h = x3_pack(v, 0.f) & 0xffffu;
+  const float r = v - __uint_as_float(h << 16);
+  const unsigned int m = x3_pack(r, 0.f) & 0xffffu;
+  const float q = r - __uint_as_float(m << 16);
+  s0 = (unsigned short)h; s1 = (unsigned short)m; s2 = (unsigned short)(x3_pack(q, 0.f) & 0xffffu);
+}
+
+// acc += A * B with the six partial products (A, B given as their three fragments)
+__device__ __forceinline__ void x3_mfma6(f32x16& acc, const u32x4 a0, const u32x4 a1, const u32x4 a2, const u32x4 b0,
+                                         const u32x4 b1, const u32x4 b2) {
+#define X3_MF(A, B) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), acc, 0, 0, 0)
+  X3_MF(a2, b0); X3_MF(a1, b1); X3_MF(a0, b2);       // smallest terms first
+  X3_MF(a1, b0); X3_MF(a0, b1);
+  X3_MF(a0, b0);
+#undef X3_MF
+}
+
+// The weights as the kernels want them in LDS -- split into bf16 pieces and permuted to the MFMA fragment order -- are
+// built ONCE per call by a small kernel (x3_prep_*) into a global image that every workgroup then copies with 16-byte
+// loads; splitting in every workgroup cost 50-100 us per launch, which is most of a sparse step.
+template <int WIDTH, int KS1>
+struct X3Img {
+  static constexpr int T = WIDTH / 32;
+  u32x4 w1s[T][KS1][3][64];          // [out tile][k-step][piece][lane]: A fragments of layer 1 (k = 16 s + 8 h + j)
+  u32x4 w2s[T][2 * T][3][64];        // [out tile][k-step = 2 t_in + s2][piece][lane]: A fragments of layer 2, k order of
+                                     //   the accumulator chain: k = 32 t_in + 16 s2 + 8 (j >> 2) + 4 h + (j & 3)
+  float w3p[3][2][T * 16];           // [c][lane half][in tile * 16 + reg]
+  float b1p[2][T * 16];              // accumulator-layout biases
+  float b2p[2][T * 16];
+  float b3[4];
+};
+
+template <int WIDTH, int KS1>
+struct X3Lds : X3Img<WIDTH, KS1> {
+  float stage[X3_WAVES][X3_STAGE_ROWS * X3_STAGE_STRIDE];
+};
+
+template <typename Img>
+__device__ __forceinline__ void x3_copy_image(Img* __restrict__ dst /* LDS */, const void* __restrict__ src) {
+  static_assert(sizeof(Img) % 16 == 0, "16-byte pieces");
+  const u32x4* g = reinterpret_cast<const u32x4*>(src);
+  u32x4* l = reinterpret_cast<u32x4*>(dst);
+  for (int i = threadIdx.x; i < (int)(sizeof(Img) / 16); i += blockDim.x) l[i] = g[i];
+}
+
+// Row-major store of one 32 (sample) x 32 (feature) accumulator tile through a wave-private LDS patch, 16 rows at a time
+// (see shade.hip shade_store_tile: a direct store would touch 32 rows x 32 B per wave instruction).
+__device__ __forceinline__ void x3_store_tile(float* __restrict__ stage, const f32x16& acc, float* __restrict__ dst, int row_stride,
+                                              int lane, int rows_valid) {
+  const int smp = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    if ((smp >> 4) == half) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4*>(stage + (smp & 15) * X3_STAGE_STRIDE + 8 * q + 4 * h) =
+            make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+    }
+    const int c = lane & 7;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int rl = (lane >> 3) + 8 * i;
+      const float4 v = *reinterpret_cast<const float4*>(stage + rl * X3_STAGE_STRIDE + 4 * c);
+      const int r = 16 * half + rl;
+      if (r < rows_valid) *reinterpret_cast<float4*>(dst + (int64_t)r * row_stride + 4 * c) = v;
+    }
+  }
+}
+
+template <int WIDTH, int KS1>
+__global__ void __launch_bounds__(256)
+x3_prep_fwd_kernel(X3Img<WIDTH, KS1>* __restrict__ Lp, const float* __restrict__ W1, const float* __restrict__ b1,
+                   const float* __restrict__ W2, const float* __restrict__ b2, const float* __restrict__ W3,
+                   const float* __restrict__ b3, int D_in) {
+  constexpr int T = WIDTH / 32;
+  X3Img<WIDTH, KS1>& L = *Lp;
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+  for (int i = tid; i < T * KS1 * 64 * 8; i += nt) {
+    const int j = i & 7, l = (i >> 3) & 63, s = (i >> 9) % KS1, t = (i >> 9) / KS1;
+    const int k = 16 * s + 8 * (l >> 5) + j;
+    const float v = (k < D_in) ? W1[(32 * t + (l & 31)) * D_in + k] : 0.0f;
+    unsigned short p0, p1, p2;
+    x3_split1(v, p0, p1, p2);
+    reinterpret_cast<unsigned short*>(&L.w1s[t][s][0][l])[j] = p0;
+    reinterpret_cast<unsigned short*>(&L.w1s[t][s][1][l])[j] = p1;
+    reinterpret_cast<unsigned short*>(&L.w1s[t][s][2][l])[j] = p2;
+  }
+  for (int i = tid; i < T * 2 * T * 64 * 8; i += nt) {
+    const int j = i & 7, l = (i >> 3) & 63, ks = (i >> 9) % (2 * T), t2 = (i >> 9) / (2 * T);
+    const int k = 16 * ks + 8 * (j >> 2) + 4 * (l >> 5) + (j & 3);          // = 32 t_in + 16 s2 + ...
+    const float v = W2[(32 * t2 + (l & 31)) * WIDTH + k];
+    unsigned short p0, p1, p2;
+    x3_split1(v, p0, p1, p2);
+    reinterpret_cast<unsigned short*>(&L.w2s[t2][ks][0][l])[j] = p0;
+    reinterpret_cast<unsigned short*>(&L.w2s[t2][ks][1][l])[j] = p1;
+    reinterpret_cast<unsigned short*>(&L.w2s[t2][ks][2][l])[j] = p2;
+  }
+  for (int i = tid; i < 3 * 2 * T * 16; i += nt) {
+    const int tr = i % (T * 16), h = (i / (T * 16)) & 1, c = i / (2 * T * 16);
+    (&L.w3p[0][0][0])[i] = W3[c * WIDTH + x3_acc_feature(tr >> 4, tr & 15, h)];
+  }
+  for (int i = tid; i < 2 * T * 16; i += nt) {
+    const int tr = i % (T * 16), h = i / (T * 16);
+    const int f = x3_acc_feature(tr >> 4, tr & 15, h);
+    (&L.b1p[0][0])[i] = b1[f];
+    (&L.b2p[0][0])[i] = b2[f];
+  }
+  if (tid < 4) L.b3[tid] = tid < 3 ? b3[tid] : 0.0f;
+}
+
+template <int WIDTH, int KS1, bool DIFFUSE>
+__global__ void __launch_bounds__(X3_THREADS)
+shade_fwd_x3_kernel(const float* __restrict__ feat, int C, int c_view0, int n_view, const float* __restrict__ emb, int E,
+                    const int64_t* __restrict__ ray_id, int64_t M, const void* __restrict__ image, float* __restrict__ rgb,
+                    float* __restrict__ H1, float* __restrict__ H2, unsigned long long* __restrict__ masks, int experiment) {
+  constexpr int T = WIDTH / 32;
+  __shared__ __attribute__((aligned(16))) X3Lds<WIDTH, KS1> L;
+  x3_copy_image<X3Img<WIDTH, KS1>>(&L, image);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, h = lane >> 5;
+  float* stage = L.stage[threadIdx.x >> 6];
+  const bool train = H1 != nullptr;
+  const int64_t n_tiles = (M + 31) / 32;
+  const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t nw = (int64_t)gridDim.x * (blockDim.x >> 6);
+  for (int64_t tile = gw; tile < n_tiles; tile += nw) {
+    const int64_t row = tile * 32 + (lane & 31);
+    const bool valid = row < M;
+    const int64_t rowc = valid ? row : (M - 1);
+    const int rows_valid = (int)(M - tile * 32 < 32 ? M - tile * 32 : 32);
+    // ---- X^T fragments of layer 1: element j of k-step s = input feature k = 16 s + 8 h + j of this lane's row:
+    //   k < n_view      : feat[row, c_view0 + k]          (k0_view,  lib/dvgo.py:518-523)
+    //   k < n_view + E  : emb[ray_id[row], k - n_view]    (viewdirs_emb[ray_id], lib/dvgo.py:524-526)
+    u32x4 x3[KS1][3];
+    {
+      const float* fr = feat + rowc * C + c_view0;
+      const float* er = emb + ray_id[rowc] * E - n_view;
+      const int d_in = n_view + E;
+#pragma unroll
+      for (int s = 0; s < KS1; ++s) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {          // branch-free: every lane loads from a valid address, then selects
+          const int k = 16 * s + 8 * h + j;
+          const int kc = k < d_in ? k : d_in - 1;
+          const float val = (experiment & 256) ? 0.01f * (float)(lane + k) : *((kc < n_view) ? fr + kc : er + kc);
+          v[j] = k < d_in ? val : 0.0f;
+        }
+        x3_split8(v, x3[s][0], x3[s][1], x3[s][2]);
+      }
+    }
+    // ---- layer 1: all WIDTH features (every layer-2 output needs them)
+    u32x4 h3[2 * T][3];                       // its post-ReLU activations as the B fragments of layer 2
+    unsigned long long mask1 = 0ull;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = L.b1p[h][t * 16 + r];
+#pragma unroll
+      for (int s = 0; s < KS1; ++s)
+        x3_mfma6(acc, L.w1s[t][s][0][lane], L.w1s[t][s][1][lane], L.w1s[t][s][2][lane], x3[s][0], x3[s][1], x3[s][2]);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = fmaxf(acc[r], 0.0f);
+      if (train) {                             // post-ReLU activations (weight gradients) + their sign bits
+        unsigned int bits = 0u;                // (after the ReLU: positive <=> bit pattern non-zero; -0 cannot occur)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bits |= min(__float_as_uint(acc[r]), 1u) << r;
+        mask1 |= (unsigned long long)bits << (16 * t);
+        if (!(experiment & 512)) x3_store_tile(stage, acc, H1 + tile * 32 * WIDTH + 32 * t, WIDTH, lane, rows_valid);
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = acc[8 * s2 + j];
+        x3_split8(v, h3[2 * t + s2][0], h3[2 * t + s2][1], h3[2 * t + s2][2]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- layer 2, one 32-feature output tile at a time, consumed immediately (H2 store, its share of layer 3)
+    float p[3] = {0.0f, 0.0f, 0.0f};
+    unsigned long long mask2 = 0ull;
+#pragma unroll 1
+    for (int t2 = 0; t2 < T; ++t2) {
+      f32x16 acc2;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[r] = L.b2p[h][t2 * 16 + r];
+      // the A fragments of k-step ks + 1 are requested before the MFMAs of k-step ks (explicit double buffer: left to
+      // itself the scheduler either hoists every read of the tile -- spills -- or none -- an LDS round trip per k-step)
+      u32x4 a[2][3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) a[0][q] = L.w2s[t2][0][q][lane];
+#pragma unroll
+      for (int ks = 0; ks < 2 * T; ++ks) {
+        if (ks + 1 < 2 * T) {
+#pragma unroll
+          for (int q = 0; q < 3; ++q) a[(ks + 1) & 1][q] = L.w2s[t2][ks + 1][q][lane];
+        }
+        x3_mfma6(acc2, a[ks & 1][0], a[ks & 1][1], a[ks & 1][2], h3[ks][0], h3[ks][1], h3[ks][2]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[r] = fmaxf(acc2[r], 0.0f);
+      if (train) {
+        unsigned int bits = 0u;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bits |= min(__float_as_uint(acc2[r]), 1u) << r;
+        mask2 |= (unsigned long long)bits << (16 * t2);
+        if (!(experiment & 512)) x3_store_tile(stage, acc2, H2 + tile * 32 * WIDTH + 32 * t2, WIDTH, lane, rows_valid);
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) p[c] = fmaf(L.w3p[c][h][t2 * 16 + r], acc2[r], p[c]);
+      }
+    }
+    float z[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) z[c] = p[c] + __shfl_xor(p[c], 32) + L.b3[c];
+    if (valid) {
+      if (h == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float zz = DIFFUSE ? z[c] + feat[row * C + c] : z[c];
+          rgb[row * 3 + c] = 1.0f / (1.0f + expf(-zz));
+        }
+      }
+      if (train) {
+        masks[(row * 2 + 0) * 2 + h] = mask1;
+        masks[(row * 2 + 1) * 2 + h] = mask2;
+      }
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------
+// Backward, data-gradient part (shade.hip shade_bwd_kernel on the split operands).  Per 32-row tile:
+//   gz  = g_rgb * rgb * (1 - rgb)
+//   G2  = (H2 > 0) * (W3^T gz)                 VALU, accumulator layout; its registers 8s..8s+7, split, are the B fragments of
+//   G1  = (H1 > 0) * (W2^T G2)                 bf16 MFMA x 6, A = W2^T pre-split / pre-permuted to the accumulator's k order
+//   gx  = W1[:, :32]^T G1                      the same chaining once more (only the feature-grid inputs need a gradient)
+// G1 and gz are written out for the weight gradients; the sign bits of H1 / H2 come from the forward's masks.
+// ----------------------------------------------------------------------------------
+template <int WIDTH>
+struct X3BwdImg {
+  static constexpr int T = WIDTH / 32;
+  u32x4 w2t[T][2 * T][3][64];      // [in tile][k-step over f_out][piece][lane]: A[i = f_in][k] = W2[f_out(k)][32 tin + i]
+  u32x4 w1t[2 * T][3][64];         // [k-step over f][piece][lane]:              A[i = k_in][k] = W1[f(k)][i]   (i < D_in else 0)
+  float w3p[3][2][T * 16];
+};
+
+template <int WIDTH>
+struct X3BwdLds : X3BwdImg<WIDTH> {
+  float stage[X3_WAVES][X3_STAGE_ROWS * X3_STAGE_STRIDE];
+};
+
+template <int WIDTH>
+__global__ void __launch_bounds__(256)
+x3_prep_bwd_kernel(X3BwdImg<WIDTH>* __restrict__ Lp, const float* __restrict__ W1, const float* __restrict__ W2,
+                   const float* __restrict__ W3, int D_in) {
+  constexpr int T = WIDTH / 32;
+  X3BwdImg<WIDTH>& L = *Lp;
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+  for (int i = tid; i < T * 2 * T * 64 * 8; i += nt) {
+    const int j = i & 7, l = (i >> 3) & 63, ks = (i >> 9) % (2 * T), tin = (i >> 9) / (2 * T);
+    const int f_out = 16 * ks + 8 * (j >> 2) + 4 * (l >> 5) + (j & 3);
+    unsigned short p0, p1, p2;
+    x3_split1(W2[f_out * WIDTH + 32 * tin + (l & 31)], p0, p1, p2);
+    reinterpret_cast<unsigned short*>(&L.w2t[tin][ks][0][l])[j] = p0;
+    reinterpret_cast<unsigned short*>(&L.w2t[tin][ks][1][l])[j] = p1;
+    reinterpret_cast<unsigned short*>(&L.w2t[tin][ks][2][l])[j] = p2;
+  }
+  for (int i = tid; i < 2 * T * 64 * 8; i += nt) {
+    const int j = i & 7, l = (i >> 3) & 63, ks = i >> 9;
+    const int f = 16 * ks + 8 * (j >> 2) + 4 * (l >> 5) + (j & 3), k = l & 31;
+    unsigned short p0, p1, p2;
+    x3_split1((k < D_in) ? W1[f * D_in + k] : 0.0f, p0, p1, p2);
+    reinterpret_cast<unsigned short*>(&L.w1t[ks][0][l])[j] = p0;
+    reinterpret_cast<unsigned short*>(&L.w1t[ks][1][l])[j] = p1;
+    reinterpret_cast<unsigned short*>(&L.w1t[ks][2][l])[j] = p2;
+  }
+  for (int i = tid; i < 3 * 2 * T * 16; i += nt) {
+    const int tr = i % (T * 16), h = (i / (T * 16)) & 1, c = i / (2 * T * 16);
+    (&L.w3p[0][0][0])[i] = W3[c * WIDTH + x3_acc_feature(tr >> 4, tr & 15, h)];
+  }
+}
+
+template <int WIDTH, bool DIFFUSE>
+__global__ void __launch_bounds__(X3_THREADS)
+shade_bwd_x3_kernel(const float* __restrict__ g_rgb, const float* __restrict__ rgb,
+                    const unsigned long long* __restrict__ masks, int64_t M, const void* __restrict__ image, int C, int c_view0,
+                    int n_view, float* __restrict__ g_feat, float* __restrict__ G1, float* __restrict__ gz_out) {
+  constexpr int T = WIDTH / 32;
+  __shared__ __attribute__((aligned(16))) X3BwdLds<WIDTH> L;
+  x3_copy_image<X3BwdImg<WIDTH>>(&L, image);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, h = lane >> 5;
+  float* stage = L.stage[threadIdx.x >> 6];
+  const int64_t n_tiles = (M + 31) / 32;
+  const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t nw = (int64_t)gridDim.x * (blockDim.x >> 6);
+  for (int64_t tile = gw; tile < n_tiles; tile += nw) {
+    const int64_t row = tile * 32 + (lane & 31);
+    const bool valid = row < M;
+    const int64_t rowc = valid ? row : (M - 1);
+    const int rows_valid = (int)(M - tile * 32 < 32 ? M - tile * 32 : 32);
+    float gz[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float o = rgb[rowc * 3 + c];
+      gz[c] = valid ? g_rgb[rowc * 3 + c] * o * (1.0f - o) : 0.0f;
+    }
+    if (valid && h == 0) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        gz_out[row * 3 + c] = gz[c];
+        if (DIFFUSE) g_feat[row * C + c] = gz[c];
+      }
+    }
+    // ReLU sign bits of this lane's 64 features per layer (bit 16*t + r <-> feature f(t,r,h))
+    const unsigned long long m1 = masks[(rowc * 2 + 0) * 2 + h];
+    const unsigned long long m2 = masks[(rowc * 2 + 1) * 2 + h];
+    // G2 in accumulator layout, split into the B fragments of the W2^T product as it is formed
+    u32x4 g3[2 * T][3];
+#pragma unroll
+    for (int t2 = 0; t2 < T; ++t2) {
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int r = 8 * s2 + j;
+          const float w = fmaf(L.w3p[2][h][t2 * 16 + r], gz[2],
+                               fmaf(L.w3p[1][h][t2 * 16 + r], gz[1], L.w3p[0][h][t2 * 16 + r] * gz[0]));
+          v[j] = ((m2 >> (16 * t2 + r)) & 1ull) ? w : 0.0f;       // gz == 0 on rows past M, so G2 == 0 there
+        }
+        x3_split8(v, g3[2 * t2 + s2][0], g3[2 * t2 + s2][1], g3[2 * t2 + s2][2]);
+      }
+    }
+    f32x16 gx;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gx[r] = 0.0f;
+#pragma unroll 1
+    for (int tin = 0; tin < T; ++tin) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+      for (int ks = 0; ks < 2 * T; ++ks) {
+        x3_mfma6(acc, L.w2t[tin][ks][0][lane], L.w2t[tin][ks][1][lane], L.w2t[tin][ks][2][lane], g3[ks][0], g3[ks][1], g3[ks][2]);
+        if (ks & 1) __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const unsigned int mb = (unsigned int)(m1 >> (16 * tin + 4 * q)) & 15u;
+        acc[4 * q + 0] = (mb & 1u) ? acc[4 * q + 0] : 0.0f;
+        acc[4 * q + 1] = (mb & 2u) ? acc[4 * q + 1] : 0.0f;
+        acc[4 * q + 2] = (mb & 4u) ? acc[4 * q + 2] : 0.0f;
+        acc[4 * q + 3] = (mb & 8u) ? acc[4 * q + 3] : 0.0f;
+      }
+      x3_store_tile(stage, acc, G1 + tile * 32 * WIDTH + 32 * tin, WIDTH, lane, rows_valid);
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = acc[8 * s2 + j];
+        u32x4 b0, b1, b2;
+        x3_split8(v, b0, b1, b2);
+        const int ks = 2 * tin + s2;
+        x3_mfma6(gx, L.w1t[ks][0][lane], L.w1t[ks][1][lane], L.w1t[ks][2][lane], b0, b1, b2);
+      }
+    }
+    if (valid) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int k = (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (k < n_view) g_feat[row * C + c_view0 + k] = gx[r];
+      }
+    }
+  }
+}
+
+extern "C" {
+
+// bytes of scratch the bf16 variants need per call (the weight image of the larger of the two kernels)
+int64_t dvgo_shade_scratch_bytes(int width) {
+  if (width == 128) return (int64_t)sizeof(X3Img<128, 3>) > (int64_t)sizeof(X3BwdImg<128>) ? sizeof(X3Img<128, 3>) : sizeof(X3BwdImg<128>);
+  if (width == 64) return (int64_t)sizeof(X3Img<64, 3>) > (int64_t)sizeof(X3BwdImg<64>) ? sizeof(X3Img<64, 3>) : sizeof(X3BwdImg<64>);
+  return 0;
+}
+
+int dvgo_shade_fwd_x3(const float* feat, int C, const float* emb, int E, const int64_t* ray_id, int64_t M,
+                      const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
+                      const float* b3, int width, int d_in, int diffuse, float* rgb, float* H1, float* H2,
+                      uint64_t* masks, void* scratch, int experiment, void* stream) {
+  if (M < 0 || C <= 0 || E < 0) return DVGO_EINVAL;
+  if (M == 0) return 0;
+  if (!feat || !emb || !ray_id || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !rgb || !scratch) return DVGO_EINVAL;
+  if ((H1 == nullptr) != (H2 == nullptr) || (H1 == nullptr) != (masks == nullptr)) return DVGO_EINVAL;
+  const int c_view0 = diffuse ? 3 : 0;
+  const int n_view = C - c_view0;
+  if (n_view < 0 || d_in != n_view + E) return DVGO_EINVAL;
+  if ((width != 128 && width != 64) || d_in > 48) return DVGO_ERANGE;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t n_tiles = (M + 31) / 32;
+  const int64_t cap = 256;                                   // one workgroup per CU (the split weights fill the LDS)
+  const int blocks = (int)((n_tiles + X3_WAVES - 1) / X3_WAVES < cap ? (n_tiles + X3_WAVES - 1) / X3_WAVES : cap);
+#define DVGO_SHADE_X3(W, KS, DIFF)                                                                                       \
+  do {                                                                                                                   \
+    x3_prep_fwd_kernel<W, KS><<<32, 256, 0, s>>>((X3Img<W, KS>*)scratch, W1, b1, W2, b2, W3, b3, d_in);                \
+    shade_fwd_x3_kernel<W, KS, DIFF><<<blocks, X3_THREADS, 0, s>>>(feat, C, c_view0, n_view, emb, E, ray_id, M, scratch, rgb, \
+                                                                    H1, H2, (unsigned long long*)masks, experiment);     \
+  } while (0)
+  if (width == 128) {
+    if (diffuse) DVGO_SHADE_X3(128, 3, true); else DVGO_SHADE_X3(128, 3, false);
+  } else {
+    if (d_in <= 16) { if (diffuse) DVGO_SHADE_X3(64, 1, true); else DVGO_SHADE_X3(64, 1, false); }
+    else            { if (diffuse) DVGO_SHADE_X3(64, 3, true); else DVGO_SHADE_X3(64, 3, false); }
+  }
+#undef DVGO_SHADE_X3
+  DVGO_LAUNCH_CHECK();
+  return 0;
+}
+
+int dvgo_shade_bwd_x3(const float* g_rgb, const float* rgb, const uint64_t* masks, int64_t M,
+                      const float* W1, const float* W2, const float* W3, int width, int d_in, int C, int diffuse,
+                      float* g_feat, float* G1, float* gz, void* scratch, void* stream) {
+  if (M < 0 || C <= 0) return DVGO_EINVAL;
+  if (M == 0) return 0;
+  if (!g_rgb || !rgb || !masks || !W1 || !W2 || !W3 || !g_feat || !G1 || !gz || !scratch) return DVGO_EINVAL;
+  const int c_view0 = diffuse ? 3 : 0;
+  const int n_view = C - c_view0;
+  if ((width != 128 && width != 64) || n_view < 0 || n_view > 32 || d_in < n_view) return DVGO_ERANGE;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t n_tiles = (M + 31) / 32;
+  const int64_t cap = 256;
+  const int blocks = (int)((n_tiles + X3_WAVES - 1) / X3_WAVES < cap ? (n_tiles + X3_WAVES - 1) / X3_WAVES : cap);
+#define DVGO_SHADE_BWD_X3(W, DIFF)                                                                                        \
+  do {                                                                                                                    \
+    x3_prep_bwd_kernel<W><<<32, 256, 0, s>>>((X3BwdImg<W>*)scratch, W1, W2, W3, d_in);                                  \
+    shade_bwd_x3_kernel<W, DIFF><<<blocks, X3_THREADS, 0, s>>>(g_rgb, rgb, (const unsigned long long*)masks, M, scratch, C, \
+                                                                c_view0, n_view, g_feat, G1, gz);                         \
+  } while (0)
+  if (width == 128) { if (diffuse) DVGO_SHADE_BWD_X3(128, true); else DVGO_SHADE_BWD_X3(128, false); }
+  else              { if (diffuse) DVGO_SHADE_BWD_X3(64, true); else DVGO_SHADE_BWD_X3(64, false); }
+#undef DVGO_SHADE_BWD_X3
+  DVGO_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // extern "C"

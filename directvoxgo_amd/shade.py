@@ -5,6 +5,8 @@
 kernel.  It applies to the reference's default head, Sequential(Linear, ReLU, Sequential(Linear, ReLU),
 Linear) with width 128 or 64; other shapes return None and the caller keeps the torch modules.
 """
+import ctypes
+
 import torch
 import torch.nn as nn
 
@@ -96,23 +98,35 @@ def head_layers(rgbnet):
     return a, mid[0], c
 
 
+def _scratch(width, device):
+    """Device scratch for the bf16-split kernels' weight image (csrc/shade_x3.hip): a fresh block per call from torch's
+    caching allocator, so that calls on different streams never share one."""
+    lib = L.lib()
+    lib.dvgo_shade_scratch_bytes.restype = ctypes.c_int64
+    n = int(lib.dvgo_shade_scratch_bytes(int(width)))
+    return torch.empty(n, dtype=torch.uint8, device=device) if n > 0 else None
+
+
 class _Shade(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, feat, emb, ray_id, W1, b1, W2, b2, W3, b3, diffuse):
+    def forward(ctx, feat, emb, ray_id, W1, b1, W2, b2, W3, b3, diffuse, train):
         M, C = feat.shape
         E = emb.shape[1]
         width, d_in = W1.shape
         feat, emb = feat.contiguous(), emb.contiguous()
-        train = any(ctx.needs_input_grad)
+        # `train`: grad mode was on at the call (inside forward() it is always off, and needs_input_grad is set for
+        # the parameters even under torch.no_grad()): rendering must not pay the 1 KB / sample of activation stores
+        train = bool(train) and any(ctx.needs_input_grad)
         rgb = torch.empty((M, 3), dtype=torch.float32, device=feat.device)
         H1 = torch.empty((M, width), dtype=torch.float32, device=feat.device) if train else None
         H2 = torch.empty((M, width), dtype=torch.float32, device=feat.device) if train else None
         masks = torch.empty((M, 4), dtype=torch.int64, device=feat.device) if train else None
+        scratch = _scratch(width, feat.device)
         with L.device_of(feat):
             L.call('dvgo_shade_fwd', ptr(feat), _int(C), ptr(emb), _int(E), ptr(ray_id), _i64(M), ptr(W1.contiguous()),
                    ptr(b1.contiguous()), ptr(W2.contiguous()), ptr(b2.contiguous()), ptr(W3.contiguous()),
                    ptr(b3.contiguous()), _int(width), _int(d_in), _int(1 if diffuse else 0), ptr(rgb), ptr(H1), ptr(H2),
-                   ptr(masks), stream_of(feat))
+                   ptr(masks), ptr(scratch), stream_of(feat))
         if train:
             ctx.save_for_backward(feat, emb, ray_id, W1, W2, W3, rgb, H1, H2, masks)
             ctx.diffuse = diffuse
@@ -129,10 +143,11 @@ class _Shade(torch.autograd.Function):
         g_feat = torch.empty_like(feat)
         G1 = torch.empty_like(H1)
         gz = torch.empty_like(rgb)
+        scratch = _scratch(width, feat.device)
         with L.device_of(feat):
             L.call('dvgo_shade_bwd', ptr(g_rgb.contiguous()), ptr(rgb), ptr(masks), _i64(M), ptr(W1.contiguous()),
                    ptr(W2.contiguous()), ptr(W3.contiguous()), _int(width), _int(d_in), _int(C), _int(1 if diffuse else 0),
-                   ptr(g_feat), ptr(G1), ptr(gz), stream_of(feat))
+                   ptr(g_feat), ptr(G1), ptr(gz), ptr(scratch), stream_of(feat))
 
         def wgrad():
             n_parts = max(1, min(N_PARTS, (M + 255) // 256))      # >= 8 row tiles per workgroup on small batches
@@ -154,9 +169,9 @@ class _Shade(torch.autograd.Function):
         gf = g_feat if ctx.needs_input_grad[0] else None
         if defer_wgrad._active is not None:
             defer_wgrad._active.submit(ctx.params, wgrad, feat.device)
-            return (gf, None, None, None, None, None, None, None, None, None)
+            return (gf, None, None, None, None, None, None, None, None, None, None)
         gW1, gb1, gW2, gb2, gW3, gb3 = wgrad()
-        return (gf, None, None, gW1, gb1, gW2, gb2, gW3, gb3, None)
+        return (gf, None, None, gW1, gb1, gW2, gb2, gW3, gb3, None, None)
 
 
 def shade(rgbnet, feat, emb, ray_id, diffuse):
@@ -169,4 +184,5 @@ def shade(rgbnet, feat, emb, ray_id, diffuse):
     c0 = 3 if diffuse else 0
     if l1.in_features != feat.shape[1] - c0 + emb.shape[1]:
         return None
-    return _Shade.apply(feat, emb, ray_id, l1.weight, l1.bias, l2.weight, l2.bias, l3.weight, l3.bias, diffuse)
+    return _Shade.apply(feat, emb, ray_id, l1.weight, l1.bias, l2.weight, l2.bias, l3.weight, l3.bias, diffuse,
+                        torch.is_grad_enabled())

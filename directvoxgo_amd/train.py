@@ -193,6 +193,7 @@ class TrainStep:
     # PROBE_EVERY steps while the dense path is in use).
     TOUCHED_MAX = 0.35
     PROBE_EVERY = 64
+    OVERLAP_MIN_SAMPLES = 600000
 
     def _rows(self):
         """(k0.grad as [n_vox, C] rows, density.grad as [n_vox]) when both share the lattice and are row-addressable."""
@@ -307,7 +308,10 @@ class TrainStep:
         opt = self.optimizer
         rows = (grid_rows_capture(density, k0, adam=(lambda: opt.grid_step_args(density, k0)) if fuse_adam else None)
                 if use_rows else contextlib.nullcontext())
-        with defer_wgrad(side_stream=self.overlap_wgrad and self.world == 1) as deferred, rows as cap:
+        # the second stream pays on kernel-bound steps (the weight-gradient kernel beside the grid scatter: -0.3 ms at
+        # 2 M samples) and costs on launch-bound ones (stream switches and event records on the host: +0.1 ms at 0.2 M)
+        side = self.overlap_wgrad and self.world == 1 and res['weights'].shape[0] >= self.OVERLAP_MIN_SAMPLES
+        with defer_wgrad(side_stream=side) as deferred, rows as cap:
             _FusedLoss.unit_grad = True
             try:
                 loss.backward()

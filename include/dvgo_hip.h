@@ -347,7 +347,17 @@ int dvgo_maskout_near_cam(float* density, const float* grid_x, const float* grid
 int dvgo_shade_fwd(const float* feat, int C, const float* emb, int E, const int64_t* ray_id, int64_t M,
                    const float* W1, const float* b1, const float* W2, const float* b2,
                    const float* W3, const float* b3, int width, int d_in, int diffuse,
-                   float* rgb, float* H1, float* H2, uint64_t* masks, void* stream);
+                   float* rgb, float* H1, float* H2, uint64_t* masks,
+                   void* scratch /* NULL, or dvgo_shade_scratch_bytes(width) bytes of device memory */, void* stream);
+
+/* Kernel variants of the colour head (process-global, for A/B runs; returns the previous value, negative = query):
+ *   bit 0  forward, bit 1 data gradients on the bf16 matrix cores: every fp32 operand split EXACTLY into three bf16
+ *          pieces, six partial products per k-step accumulated in fp32 (csrc/shade_x3.hip) -- fp32-grade results at 2.7x
+ *          fewer matrix-pipe cycles than v_mfma_f32_32x32x2_f32.  Default 3; the f32-MFMA kernels run when the bit is
+ *          clear or `scratch` is NULL (the bf16 variants keep the pre-split weight image there, built by a small kernel
+ *          at every call). */
+int64_t dvgo_shade_scratch_bytes(int width);
+int dvgo_shade_variant(int flags);
 
 /* Data-gradient part of the colour-head backward.  Inputs: g_rgb, rgb [M,3]; the saved activations
  * sign-bit masks written by dvgo_shade_fwd.  Outputs: gz [M,3] (= g_rgb * sigmoid'),
@@ -356,7 +366,7 @@ int dvgo_shade_fwd(const float* feat, int C, const float* emb, int E, const int6
  * channels [0,3) = gz when diffuse, channels [c0, C) = (W1^T G1)[:C-c0]. */
 int dvgo_shade_bwd(const float* g_rgb, const float* rgb, const uint64_t* masks, int64_t M,
                    const float* W1, const float* W2, const float* W3, int width, int d_in, int C, int diffuse,
-                   float* g_feat, float* G1, float* gz, void* stream);
+                   float* g_feat, float* G1, float* gz, void* scratch, void* stream);
 
 /* Weight-gradient part (G1, gz from dvgo_shade_bwd; masks, H1, H2 from dvgo_shade_fwd; W3 as given to both):
  * dW2 = G2^T H1, dW1 = G1^T X (X = the layer-1 input, re-assembled from feat / emb /

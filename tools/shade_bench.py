@@ -13,7 +13,14 @@ from directvoxgo_amd.shade import shade
 ap = argparse.ArgumentParser()
 ap.add_argument('--M', type=int, default=2097152)
 ap.add_argument('--rounds', type=int, default=10)
+ap.add_argument('--experiment', type=int, default=0)
+ap.add_argument('--variant', type=int, default=-1, help='dvgo_shade_variant bits (default: leave as is)')
 args = ap.parse_args()
+from directvoxgo_amd import _lib as L
+if args.variant >= 0:
+    L.lib().dvgo_shade_variant(args.variant)
+L.lib().dvgo_shade_experiment(args.experiment)
+print('shade variant', L.lib().dvgo_shade_variant(-1))
 torch.manual_seed(0)
 M, N = args.M, 8192
 net = make_rgbnet(39, 128, 3).cuda()          # rgbnet_direct head of configs/default.py: 12 + 27 inputs
@@ -56,8 +63,8 @@ def hip_train_fwd_bwd():
 
 
 def torch_train_fwd_bwd():
-    x = torch.cat([fg[:, 3:], emb[ray_id]], -1)
-    r = torch.sigmoid(mlp_forward(net, x) + fg[:, :3])
+    x = torch.cat([fg, emb[ray_id]], -1)
+    r = torch.sigmoid(mlp_forward(net, x))
     r.sum().backward()
 
 
