@@ -448,6 +448,21 @@ def main():
         'kernel_timing': 'HIP events around each launch, second pass of the same K steps with all kernels on one stream',
     }
 
+    from directvoxgo_amd import _lib as L_
+    variant = L_.lib().dvgo_shade_variant(-1)
+    out['config']['colour_head'] = ('fp32 operands split exactly into 3 bf16 pieces, 6 partial products per k-step on '
+                                    'v_mfma_f32_32x32x16_bf16, fp32 accumulation -- fp32-grade results, held to the same '
+                                    'tolerances as the f32-MFMA kernels (tests/test_gpu_ops.py); weight gradients on '
+                                    'v_mfma_f32_32x32x2_f32') if (variant & 3) else 'v_mfma_f32_32x32x2_f32 throughout'
+    if rank == 0 and world == 1 and not args.no_secondary and args.workload == 'roofline' and (variant & 3):
+        # the same step with the colour head entirely on the f32 MFMA (round 1's kernels), for reference
+        L_.lib().dvgo_shade_variant(0)
+        try:
+            _, _, _, dt0, _, _, _ = run(args.workload, max(args.steps // 2, 5), args.warmup, False)
+            n0 = max(args.steps // 2, 5)
+            out['colour_head_f32_mfma'] = {'value': n_total * n0 / dt0, 'unit': 'rays/s', 'ms_per_step': dt0 / n0 * 1e3}
+        finally:
+            L_.lib().dvgo_shade_variant(variant)
     if rank == 0 and world == 1 and not args.no_secondary and args.workload == 'roofline':
         sc2, m2, rk2, dt2, prof2, (M0b, M_db, M_kb), _ = run('lego', max(args.steps, 20), args.warmup, False)
         out['lego_like'] = {'value': args.rays * max(args.steps, 20) / dt2, 'unit': 'rays/s',
