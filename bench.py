@@ -357,6 +357,8 @@ def main():
     ap.add_argument('--no-secondary', action='store_true', help='skip the lego-like secondary measurement')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-rays', type=int, default=8192)
+    ap.add_argument('--graph', action='store_true',
+                    help='capture the step of the primary workload into a HIP graph (TrainStep.capture) and time the replays')
     ap.add_argument('--single-stream', action='store_true',
                     help='timed region without the second-stream overlap of the colour-head weight gradients: every launch '
                          'of a kernel then runs alone, so rocprofv3 --stats averages agree with the HIP-event averages')
@@ -385,18 +387,21 @@ def main():
 
     from directvoxgo_amd.train import FINE_TRAIN, TrainStep
 
-    def run(workload, steps, warmup, profile):
+    def run(workload, steps, warmup, profile, graph=False):
         sc, m = build(workload, args.world, args.rays, device, seed=777)
         load_state(m, sc)
         rk = dict(near=sc['near'], far=sc['far'], bg=1, stepsize=sc['stepsize'])
         pool = ray_pool(workload, float(sc['xyz_max'][0]), args.rays, device, base_seed=777 + 1000 * rank, n_batches=4)
         M0, M_d, M_k = count_samples(m, pool[0], rk)
         step = TrainStep(m, dict(FINE_TRAIN), rk, overlap_wgrad=not args.single_stream)
-        dt, prof = timed_region(step, pool, steps, warmup, world, profile)
+        captured = bool(graph) and step.capture(*pool[0], global_step=5000)
+        dt, prof = timed_region(step, pool, steps, warmup, world, profile and not captured)
+        run.captured = captured
         end_counts = count_samples(m, pool[0], rk)          # the optimizer moves the scene: how far did the workload drift?
         return sc, m, rk, dt, prof, (M0, M_d, M_k), end_counts
 
-    sc, m, rk, dt, prof, (M0, M_d, M_k), end_counts = run(args.workload, args.steps, args.warmup, True)
+    sc, m, rk, dt, prof, (M0, M_d, M_k), end_counts = run(args.workload, args.steps, args.warmup, True, graph=args.graph)
+    primary_captured = bool(getattr(run, 'captured', False))
     n_total = args.rays * world
     value = n_total * args.steps / dt
 
@@ -446,6 +451,7 @@ def main():
                    'samples_after_run': {'M_d': end_counts[1], 'M_k': end_counts[2]}},
         'roofline': roofline, 'north_star_kernels': ns, 'kernels': kernels,
         'kernel_timing': 'HIP events around each launch, second pass of the same K steps with all kernels on one stream',
+        'hip_graph': primary_captured,
     }
 
     from directvoxgo_amd import _lib as L_
@@ -464,11 +470,20 @@ def main():
         finally:
             L_.lib().dvgo_shade_variant(variant)
     if rank == 0 and world == 1 and not args.no_secondary and args.workload == 'roofline':
-        sc2, m2, rk2, dt2, prof2, (M0b, M_db, M_kb), _ = run('lego', max(args.steps, 20), args.warmup, False)
-        out['lego_like'] = {'value': args.rays * max(args.steps, 20) / dt2, 'unit': 'rays/s',
-                            'ms_per_step': dt2 / max(args.steps, 20) * 1e3, 'occupancy': sc2['occupancy'],
+        # the sparse step is launch-bound when run eagerly; measured both ways: eager, and replayed as one HIP graph
+        n2 = max(args.steps, 50)
+        sc2, m2, rk2, dt2, prof2, (M0b, M_db, M_kb), _ = run('lego', n2, args.warmup, False)
+        out['lego_like'] = {'value': args.rays * n2 / dt2, 'unit': 'rays/s',
+                            'ms_per_step': dt2 / n2 * 1e3, 'occupancy': sc2['occupancy'], 'mode': 'eager',
                             'samples_per_ray': {'M0': M0b / args.rays, 'M_d': M_db / args.rays, 'M_k': M_kb / args.rays}}
         del sc2, m2
+        try:
+            sc2, m2, rk2, dt3, _, _, _ = run('lego', n2, args.warmup, False, graph=True)
+            out['lego_like']['hip_graph'] = {'captured': bool(run.captured), 'value': args.rays * n2 / dt3, 'unit': 'rays/s',
+                                             'ms_per_step': dt3 / n2 * 1e3}
+            del sc2, m2
+        except Exception as exc:
+            out['lego_like']['hip_graph'] = {'captured': False, 'error': repr(exc)[:300]}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sc_cpu = {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in sc.items()}

@@ -69,6 +69,7 @@ march_scans_kernel(const int32_t* __restrict__ n3, int n_rays, int64_t* __restri
 struct BrickAdam {
   float *pk, *mk, *vk, *pd, *md, *vd;
   float ss_k, ss_d, beta1, beta2, eps;
+  const float* ss_dev;            // NULL, or {step size k0, step size density} on the device (captured training steps)
   int masked_k, masked_d;
 };
 
@@ -109,6 +110,7 @@ brick_accumulate_kernel(const int32_t* __restrict__ off, const int4* __restrict_
   __shared__ __attribute__((aligned(16))) Lds u;
   static_assert(sizeof(Lds) <= 40960, "4 workgroups per CU");
 
+  if (A.ss_dev != nullptr) { A.ss_k = A.ss_dev[0]; A.ss_d = A.ss_dev[1]; }
   // blocks b and b + 8 share an XCD (round-robin dispatch): give each XCD a contiguous range of bricks, so that the
   // up-to-8 bricks listing one sample read its gradient row through the same L2
   const int per = (G.nb + 7) >> 3;
@@ -370,7 +372,7 @@ int dvgo_brick_accumulate(const int32_t* brick_off, const void* recs, const floa
                           int C, int X, int Y, int Z, float* grad_k0, float* grad_density,
                           float* p_k0, float* m_k0, float* v_k0, float step_size_k0, int masked_k0,
                           float* p_density, float* m_density, float* v_density, float step_size_density,
-                          int masked_density, float beta1, float beta2, float eps, void* stream) {
+                          int masked_density, float beta1, float beta2, float eps, const float* step_sizes_dev, void* stream) {
   const int nb = dvgo_n_bricks(X, Y, Z);
   if (nb < 0) return nb;
   const bool adam = p_k0 != nullptr;
@@ -389,6 +391,7 @@ int dvgo_brick_accumulate(const int32_t* brick_off, const void* recs, const floa
   BrickAdam A;
   A.pk = p_k0; A.mk = m_k0; A.vk = v_k0; A.pd = p_density; A.md = m_density; A.vd = v_density;
   A.ss_k = step_size_k0; A.ss_d = step_size_density; A.beta1 = beta1; A.beta2 = beta2; A.eps = eps;
+  A.ss_dev = step_sizes_dev;
   A.masked_k = masked_k0; A.masked_d = masked_density;
   const int blocks = ((nb + 7) >> 3) << 3;
   hipStream_t s = (hipStream_t)stream;

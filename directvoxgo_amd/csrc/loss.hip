@@ -52,8 +52,10 @@ loss_rays_kernel(const float* __restrict__ rgb_marched, const float* __restrict_
 // (weights detached, run.py:385)
 __global__ void __launch_bounds__(256)
 loss_samples_kernel(const float* __restrict__ raw_rgb, const float* __restrict__ weights,
-                    const int64_t* __restrict__ ray_id, const float* __restrict__ target, int64_t M,
+                    const int64_t* __restrict__ ray_id, const float* __restrict__ target, int64_t M_cap,
+                    const int64_t* __restrict__ m_dev,
                     float inv_n_global, float w_per, float* __restrict__ g_raw_rgb, float* __restrict__ loss_out) {
+  const int64_t M = m_dev ? (*m_dev < M_cap ? *m_dev : M_cap) : M_cap;      // sample count kept on the device (train.py)
   __shared__ float red[4];
   float l = 0.0f;
   // grid-stride: one same-address atomic per workgroup is the cost that matters here, so few, long-lived workgroups
@@ -104,7 +106,8 @@ struct AdamMulti {
   int n;
 };
 __global__ void __launch_bounds__(256)
-adam_multi_kernel(AdamMulti A, float step_size, float beta1, float beta2, float eps) {
+adam_multi_kernel(AdamMulti A, float step_size, const float* __restrict__ step_size_dev, float beta1, float beta2, float eps) {
+  if (step_size_dev != nullptr) step_size = *step_size_dev;
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= A.start[A.n]) return;
   int k = 0;
@@ -121,7 +124,7 @@ adam_multi_kernel(AdamMulti A, float step_size, float beta1, float beta2, float 
 extern "C" {
 
 int dvgo_loss_fwd_bwd(const float* rgb_marched, const float* alphainv_last, const float* target, int64_t N,
-                      const float* raw_rgb, const float* weights, const int64_t* ray_id, int64_t M,
+                      const float* raw_rgb, const float* weights, const int64_t* ray_id, int64_t M, const int64_t* m_dev,
                       int64_t n_rays_global, float w_main, float w_ent, float w_per, float* g_marched,
                       float* g_last, float* g_raw_rgb, float* loss_out, void* stream) {
   if (N < 0 || M < 0 || n_rays_global <= 0) return DVGO_EINVAL;
@@ -138,8 +141,8 @@ int dvgo_loss_fwd_bwd(const float* rgb_marched, const float* alphainv_last, cons
   if (M > 0 && w_per > 0.0f) {
     if (!raw_rgb || !weights || !ray_id || !g_raw_rgb) return DVGO_EINVAL;
     const int64_t nb = dvgo_blocks(M, 256);
-    loss_samples_kernel<<<(int)(nb < 1024 ? nb : 1024), 256, 0, s>>>(raw_rgb, weights, ray_id, target, M, inv, w_per, g_raw_rgb,
-                                                            loss_out);
+    loss_samples_kernel<<<(int)(nb < 1024 ? nb : 1024), 256, 0, s>>>(raw_rgb, weights, ray_id, target, M, m_dev, inv, w_per,
+                                                            g_raw_rgb, loss_out);
     DVGO_LAUNCH_CHECK();
   }
   return 0;
@@ -158,7 +161,7 @@ int dvgo_viewdir_embed(const float* viewdirs, const float* freq, int n_freq, int
 
 int dvgo_adam_upd_multi(float* const* params, const float* const* grads, float* const* exp_avg,
                         float* const* exp_avg_sq, const int64_t* numel, int n_tensors, float step_size, float beta1,
-                        float beta2, float eps, void* stream) {
+                        float beta2, float eps, const float* step_size_dev, void* stream) {
   if (n_tensors < 0 || n_tensors > DVGO_MT_MAX) return DVGO_EINVAL;
   if (n_tensors == 0) return 0;
   if (!params || !grads || !exp_avg || !exp_avg_sq || !numel) return DVGO_EINVAL;
@@ -173,7 +176,7 @@ int dvgo_adam_upd_multi(float* const* params, const float* const* grads, float* 
   }
   for (int k = n_tensors; k <= DVGO_MT_MAX; ++k) A.start[k] = tot;
   if (tot == 0) return 0;
-  adam_multi_kernel<<<dvgo_blocks(tot, 256), 256, 0, (hipStream_t)stream>>>(A, step_size, beta1, beta2, eps);
+  adam_multi_kernel<<<dvgo_blocks(tot, 256), 256, 0, (hipStream_t)stream>>>(A, step_size, step_size_dev, beta1, beta2, eps);
   DVGO_LAUNCH_CHECK();
   return 0;
 }

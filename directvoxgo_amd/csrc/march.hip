@@ -412,9 +412,11 @@ march_composite_kernel(const float* __restrict__ weights, const float* __restric
 
 __global__ void __launch_bounds__(DVGO_BLOCK)
 march_composite_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ weights,
-                           const float* __restrict__ rgb, const int64_t* __restrict__ ray_id, int64_t M3,
+                           const float* __restrict__ rgb, const int64_t* __restrict__ ray_id, int64_t M_cap,
+                           const int64_t* __restrict__ m_dev,
                            float* __restrict__ grad_weights, float* __restrict__ grad_rgb, int64_t n_rays, float bg,
                            float* __restrict__ grad_last) {
+  const int64_t M3 = m_dev ? (*m_dev < M_cap ? *m_dev : M_cap) : M_cap;      // sample count kept on the device (train.py)
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   // d rgb_marched / d alphainv_last = bg (lib/dvgo.py:559): the N-sized reduction rides on the first n_rays threads
   if (grad_last != nullptr && i < n_rays) grad_last[i] = (gout[3 * i] + gout[3 * i + 1] + gout[3 * i + 2]) * bg;
@@ -858,7 +860,7 @@ int dvgo_march_composite(const float* weights, const float* rgb, const int64_t* 
 }
 
 int dvgo_march_composite_bwd(const float* grad_rgb_marched, const float* weights, const float* rgb,
-                             const int64_t* ray_id, int64_t M3, int64_t n_rays, float bg,
+                             const int64_t* ray_id, int64_t M3, const int64_t* m_dev, int64_t n_rays, float bg,
                              float* grad_weights, float* grad_rgb, float* grad_last, void* stream) {
   if (M3 < 0 || n_rays < 0) return DVGO_EINVAL;
   const int64_t n_last = grad_last ? n_rays : 0;
@@ -867,7 +869,7 @@ int dvgo_march_composite_bwd(const float* grad_rgb_marched, const float* weights
   const int64_t threads = M3 > n_last ? M3 : n_last;
   if (!dvgo_fits(threads)) return DVGO_ERANGE;
   march_composite_bwd_kernel<<<dvgo_blocks(threads, DVGO_BLOCK), DVGO_BLOCK, 0, (hipStream_t)stream>>>(
-      grad_rgb_marched, weights, rgb, ray_id, M3, grad_weights, grad_rgb, n_last, bg, grad_last);
+      grad_rgb_marched, weights, rgb, ray_id, M3, m_dev, grad_weights, grad_rgb, n_last, bg, grad_last);
   DVGO_LAUNCH_CHECK();
   return 0;
 }

@@ -25,14 +25,17 @@
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 static int g_shade_experiment = 0;   // timing experiments only (tools/): bit 0 = skip G1/G2 stores in shade_bwd
-// kernel variants (dvgo_shade_variant): bit 0 = forward, bit 1 = data gradients on the bf16 matrix cores with a 3-way
-// operand split (shade_x3.hip)
+// kernel variants (dvgo_shade_variant): bit 0 = forward, bit 1 = data gradients, bit 2 = weight gradients on the bf16
+// matrix cores with a 3-way operand split (shade_x3.hip)
 static int g_shade_variant = 3;
-extern "C" int dvgo_shade_bwd_x3(const float* g_rgb, const float* rgb, const uint64_t* masks, int64_t M,
+extern "C" int dvgo_shade_wgrad_x3(const float* G1, const float* gz, const uint64_t* masks, const float* W3, const float* H1,
+                                   const float* H2, const float* feat, int C, const float* emb, int E, const int64_t* ray_id,
+                                   int64_t M, const int64_t* m_dev, int width, int diffuse, int n_parts, float* part, void* stream);
+extern "C" int dvgo_shade_bwd_x3(const float* g_rgb, const float* rgb, const uint64_t* masks, int64_t M, const int64_t* m_dev,
                                  const float* W1, const float* W2, const float* W3, int width, int d_in, int C, int diffuse,
                                  float* g_feat, float* G1, float* gz, void* scratch, void* stream);
 
-extern "C" int dvgo_shade_fwd_x3(const float* feat, int C, const float* emb, int E, const int64_t* ray_id, int64_t M,
+extern "C" int dvgo_shade_fwd_x3(const float* feat, int C, const float* emb, int E, const int64_t* ray_id, int64_t M, const int64_t* m_dev,
                                  const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
                                  const float* b3, int width, int d_in, int diffuse, float* rgb, float* H1, float* H2,
                                  uint64_t* masks, void* scratch, int experiment, void* stream);
@@ -192,10 +195,11 @@ __device__ __forceinline__ void shade_load_x(const float* __restrict__ feat, int
 template <int WIDTH, int S1, bool DIFFUSE>
 __global__ void __launch_bounds__(SHADE_THREADS)
 shade_fwd_kernel(const float* __restrict__ feat, int C, int c_view0, int n_view, const float* __restrict__ emb, int E,
-                 const int64_t* __restrict__ ray_id, int64_t M, const float* __restrict__ W1,
+                 const int64_t* __restrict__ ray_id, int64_t M_cap, const int64_t* __restrict__ m_dev, const float* __restrict__ W1,
                  const float* __restrict__ b1, const float* __restrict__ W2, const float* __restrict__ b2,
                  const float* __restrict__ W3, const float* __restrict__ b3, int D_in, float* __restrict__ rgb,
                  float* __restrict__ H1, float* __restrict__ H2, unsigned long long* __restrict__ masks, int experiment) {
+  const int64_t M = m_dev ? (*m_dev < M_cap ? *m_dev : M_cap) : M_cap;      // sample count kept on the device (train.py)
   constexpr int T = WIDTH / 32;
   __shared__ ShadeLds<WIDTH, S1> L;
   __shared__ __attribute__((aligned(16))) float s_stage[SHADE_WAVES][32 * SHADE_STAGE_STRIDE];
@@ -268,9 +272,11 @@ struct ShadeBwdLds {
 template <int WIDTH, bool DIFFUSE>
 __global__ void __launch_bounds__(SHADE_BWD_THREADS)
 shade_bwd_kernel(const float* __restrict__ g_rgb, const float* __restrict__ rgb,
-                 const unsigned long long* __restrict__ masks, int64_t M, const float* __restrict__ W1, const float* __restrict__ W2,
+                 const unsigned long long* __restrict__ masks, int64_t M_cap, const int64_t* __restrict__ m_dev,
+                 const float* __restrict__ W1, const float* __restrict__ W2,
                  const float* __restrict__ W3, int D_in, int C, int c_view0, int n_view,
                  float* __restrict__ g_feat, float* __restrict__ G1, float* __restrict__ gz_out, int experiment) {
+  const int64_t M = m_dev ? (*m_dev < M_cap ? *m_dev : M_cap) : M_cap;      // sample count kept on the device (train.py)
   constexpr int T = WIDTH / 32;
   __shared__ ShadeBwdLds<WIDTH> L;
   __shared__ __attribute__((aligned(16))) float s_stage[SHADE_BWD_WAVES][32 * SHADE_STAGE_STRIDE];
@@ -400,7 +406,9 @@ __global__ void __launch_bounds__(2 * WIDTH) __attribute__((amdgpu_num_vgpr(104)
 shade_wgrad_kernel(const float* __restrict__ G1, const float* __restrict__ gz, const unsigned int* __restrict__ masks,
                    const float* __restrict__ W3, const float* __restrict__ H1, const float* __restrict__ H2, const float* __restrict__ feat, int C,
                    int c_view0, int n_view, const float* __restrict__ emb, int E, const int64_t* __restrict__ ray_id,
-                   int64_t M, float* __restrict__ part /* [gridDim][WIDTH*WIDTH + WIDTH*64 + 32*WIDTH + 3*WIDTH] */) {
+                   int64_t M_cap, const int64_t* __restrict__ m_dev,
+                   float* __restrict__ part /* [gridDim][WIDTH*WIDTH + WIDTH*64 + 32*WIDTH + 3*WIDTH] */) {
+  const int64_t M = m_dev ? (*m_dev < M_cap ? *m_dev : M_cap) : M_cap;      // sample count kept on the device (train.py)
   constexpr int T = WIDTH / 32;
   static_assert(T == 4 || T == 2, "widths 128 and 64");
   constexpr int TPR = 2 * T;                 // staging threads per X row (32 rows over the 64*T threads)
@@ -582,7 +590,7 @@ shade_wgrad_reduce_kernel(const float* __restrict__ part, int n_parts, int n, fl
 
 extern "C" {
 
-int dvgo_shade_fwd(const float* feat, int C, const float* emb, int E, const int64_t* ray_id, int64_t M,
+int dvgo_shade_fwd(const float* feat, int C, const float* emb, int E, const int64_t* ray_id, int64_t M, const int64_t* m_dev,
                    const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
                    const float* b3, int width, int d_in, int diffuse, float* rgb, float* H1, float* H2,
                    uint64_t* masks, void* scratch, void* stream) {
@@ -595,14 +603,14 @@ int dvgo_shade_fwd(const float* feat, int C, const float* emb, int E, const int6
   if (n_view < 0 || d_in != n_view + E) return DVGO_EINVAL;
   if ((width != 128 && width != 64) || d_in > 40) return DVGO_ERANGE;   // outside the instantiated set: caller falls back
   if ((g_shade_variant & 1) && scratch != nullptr)
-    return dvgo_shade_fwd_x3(feat, C, emb, E, ray_id, M, W1, b1, W2, b2, W3, b3, width, d_in, diffuse, rgb, H1, H2, masks,
+    return dvgo_shade_fwd_x3(feat, C, emb, E, ray_id, M, m_dev, W1, b1, W2, b2, W3, b3, width, d_in, diffuse, rgb, H1, H2, masks,
                              scratch, g_shade_experiment, stream);
   hipStream_t s = (hipStream_t)stream;
   const int64_t n_tiles = (M + 31) / 32;
   const int64_t cap = width == 128 ? 256 : 512;          // width 128: one workgroup per CU (LDS); width 64: two
   int blocks = (int)((n_tiles + SHADE_WAVES - 1) / SHADE_WAVES < cap ? (n_tiles + SHADE_WAVES - 1) / SHADE_WAVES : cap);
 #define DVGO_SHADE(W, S1, DIFF)                                                                           \
-  shade_fwd_kernel<W, S1, DIFF><<<blocks, SHADE_THREADS, 0, s>>>(feat, C, c_view0, n_view, emb, E, ray_id, M, W1, b1, W2, \
+  shade_fwd_kernel<W, S1, DIFF><<<blocks, SHADE_THREADS, 0, s>>>(feat, C, c_view0, n_view, emb, E, ray_id, M, m_dev, W1, b1, W2, \
                                                           b2, W3, b3, d_in, rgb, H1, H2, (unsigned long long*)masks, g_shade_experiment)
   // S1 = k-steps of layer 1 (2 inputs each, zero-padded): 128-wide head of configs/default.py: d_in 36 / 39;
   // 64-wide head of configs/llff (lib/dmpigo.py): d_in = 9 + 3
@@ -622,7 +630,7 @@ int dvgo_shade_experiment(int flags) { g_shade_experiment = flags; return 0; }
 
 int dvgo_shade_variant(int flags) { const int old = g_shade_variant; if (flags >= 0) g_shade_variant = flags; return old; }
 
-int dvgo_shade_bwd(const float* g_rgb, const float* rgb, const uint64_t* masks, int64_t M,
+int dvgo_shade_bwd(const float* g_rgb, const float* rgb, const uint64_t* masks, int64_t M, const int64_t* m_dev,
                    const float* W1, const float* W2, const float* W3, int width, int d_in, int C, int diffuse,
                    float* g_feat, float* G1, float* gz, void* scratch, void* stream) {
   if (M < 0 || C <= 0) return DVGO_EINVAL;
@@ -632,13 +640,13 @@ int dvgo_shade_bwd(const float* g_rgb, const float* rgb, const uint64_t* masks, 
   const int n_view = C - c_view0;
   if ((width != 128 && width != 64) || n_view < 0 || n_view > 32 || d_in < n_view) return DVGO_ERANGE;
   if ((g_shade_variant & 2) && scratch != nullptr)
-    return dvgo_shade_bwd_x3(g_rgb, rgb, masks, M, W1, W2, W3, width, d_in, C, diffuse, g_feat, G1, gz, scratch, stream);
+    return dvgo_shade_bwd_x3(g_rgb, rgb, masks, M, m_dev, W1, W2, W3, width, d_in, C, diffuse, g_feat, G1, gz, scratch, stream);
   hipStream_t s = (hipStream_t)stream;
   const int64_t n_tiles = (M + 31) / 32;
   const int64_t cap = width == 128 ? 256 : 512;
   int blocks = (int)((n_tiles + SHADE_BWD_WAVES - 1) / SHADE_BWD_WAVES < cap ? (n_tiles + SHADE_BWD_WAVES - 1) / SHADE_BWD_WAVES : cap);
 #define DVGO_SHADE_BWD(W, DIFF)                                                                                                       \
-  shade_bwd_kernel<W, DIFF><<<blocks, SHADE_BWD_THREADS, 0, s>>>(g_rgb, rgb, (const unsigned long long*)masks, M, W1, W2, W3, d_in, C, c_view0, \
+  shade_bwd_kernel<W, DIFF><<<blocks, SHADE_BWD_THREADS, 0, s>>>(g_rgb, rgb, (const unsigned long long*)masks, M, m_dev, W1, W2, W3, d_in, C, c_view0, \
                                                             n_view, g_feat, G1, gz, g_shade_experiment)
   if (width == 128) { if (diffuse) DVGO_SHADE_BWD(128, true); else DVGO_SHADE_BWD(128, false); }
   else              { if (diffuse) DVGO_SHADE_BWD(64, true); else DVGO_SHADE_BWD(64, false); }
@@ -648,19 +656,23 @@ int dvgo_shade_bwd(const float* g_rgb, const float* rgb, const uint64_t* masks, 
 }
 
 int dvgo_shade_wgrad(const float* G1, const float* gz, const uint64_t* masks, const float* W3, const float* H1,
-                     const float* H2, const float* feat, int C, const float* emb, int E, const int64_t* ray_id, int64_t M, int width,
-                     int diffuse, int n_parts, float* part, float* total, void* stream) {
+                     const float* H2, const float* feat, int C, const float* emb, int E, const int64_t* ray_id, int64_t M,
+                     const int64_t* m_dev, int width, int diffuse, int n_parts, float* part, float* total, void* stream) {
   if (M < 0 || n_parts <= 0 || C <= 0 || E < 0) return DVGO_EINVAL;
   if (!G1 || !gz || !masks || !W3 || !H1 || !H2 || !feat || !emb || !ray_id || !part || !total) return DVGO_EINVAL;
   const int c_view0 = diffuse ? 3 : 0;
   const int n_view = C - c_view0;
   if ((width != 128 && width != 64) || n_view < 0 || n_view + E > 40) return DVGO_ERANGE;
-  if (width == 128)
+  if (g_shade_variant & 4) {
+    if (n_parts > 256) n_parts = 256;       // one 8-wave workgroup per CU (141 KB of LDS)
+    const int rc = dvgo_shade_wgrad_x3(G1, gz, masks, W3, H1, H2, feat, C, emb, E, ray_id, M, m_dev, width, diffuse, n_parts, part, stream);
+    if (rc != 0) return rc;
+  } else if (width == 128)
     shade_wgrad_kernel<128><<<n_parts, 256, 0, (hipStream_t)stream>>>(
-        G1, gz, (const unsigned int*)masks, W3, H1, H2, feat, C, c_view0, n_view, emb, E, ray_id, M, part);
+        G1, gz, (const unsigned int*)masks, W3, H1, H2, feat, C, c_view0, n_view, emb, E, ray_id, M, m_dev, part);
   else
     shade_wgrad_kernel<64><<<n_parts, 128, 0, (hipStream_t)stream>>>(
-        G1, gz, (const unsigned int*)masks, W3, H1, H2, feat, C, c_view0, n_view, emb, E, ray_id, M, part);
+        G1, gz, (const unsigned int*)masks, W3, H1, H2, feat, C, c_view0, n_view, emb, E, ray_id, M, m_dev, part);
   DVGO_LAUNCH_CHECK();
   const int psize = width * width + width * 64 + 32 * width + 3 * width;
   if (hipMemsetAsync(total, 0, (size_t)psize * sizeof(float), (hipStream_t)stream) != hipSuccess) return DVGO_EINVAL;

@@ -161,8 +161,10 @@ x3_prep_fwd_kernel(X3Img<WIDTH, KS1>* __restrict__ Lp, const float* __restrict__
 template <int WIDTH, int KS1, bool DIFFUSE>
 __global__ void __launch_bounds__(X3_THREADS)
 shade_fwd_x3_kernel(const float* __restrict__ feat, int C, int c_view0, int n_view, const float* __restrict__ emb, int E,
-                    const int64_t* __restrict__ ray_id, int64_t M, const void* __restrict__ image, float* __restrict__ rgb,
+                    const int64_t* __restrict__ ray_id, int64_t M_cap, const int64_t* __restrict__ m_dev,
+                    const void* __restrict__ image, float* __restrict__ rgb,
                     float* __restrict__ H1, float* __restrict__ H2, unsigned long long* __restrict__ masks, int experiment) {
+  const int64_t M = m_dev ? (*m_dev < M_cap ? *m_dev : M_cap) : M_cap;      // sample count kept on the device (train.py)
   constexpr int T = WIDTH / 32;
   __shared__ __attribute__((aligned(16))) X3Lds<WIDTH, KS1> L;
   x3_copy_image<X3Img<WIDTH, KS1>>(&L, image);
@@ -339,8 +341,10 @@ x3_prep_bwd_kernel(X3BwdImg<WIDTH>* __restrict__ Lp, const float* __restrict__ W
 template <int WIDTH, bool DIFFUSE>
 __global__ void __launch_bounds__(X3_THREADS)
 shade_bwd_x3_kernel(const float* __restrict__ g_rgb, const float* __restrict__ rgb,
-                    const unsigned long long* __restrict__ masks, int64_t M, const void* __restrict__ image, int C, int c_view0,
+                    const unsigned long long* __restrict__ masks, int64_t M_cap, const int64_t* __restrict__ m_dev,
+                    const void* __restrict__ image, int C, int c_view0,
                     int n_view, float* __restrict__ g_feat, float* __restrict__ G1, float* __restrict__ gz_out) {
+  const int64_t M = m_dev ? (*m_dev < M_cap ? *m_dev : M_cap) : M_cap;      // sample count kept on the device (train.py)
   constexpr int T = WIDTH / 32;
   __shared__ __attribute__((aligned(16))) X3BwdLds<WIDTH> L;
   x3_copy_image<X3BwdImg<WIDTH>>(&L, image);
@@ -431,6 +435,242 @@ shade_bwd_x3_kernel(const float* __restrict__ g_rgb, const float* __restrict__ r
   }
 }
 
+// ----------------------------------------------------------------------------------
+// Backward, weight-gradient part on the split operands:  dW2 = G2^T H1,  dW1 = G1^T X,  dW3 = gz^T H2,  db = column sums
+// (shade.hip shade_wgrad_kernel; same inputs, same `part` record per workgroup, so the reduce kernel and the host code
+// are shared).  The contraction runs over ROWS: a 32-row tile is two 16-deep k-steps, A[i = out feature][k = row] and
+// B[k = row][j = in feature] are COLUMNS of the row-major operand tiles -- 8 rows of one column per lane -- so every
+// streamed element is split on the fly (that is the price of this orientation: the kernel is bound by the split
+// arithmetic and by the 1.5 KB / sample it streams, not by the matrix pipe).
+//   * operand tiles (G1, H1, H2: 32 x WIDTH fp32 each) go global -> LDS by LDS-DMA, double buffered;
+//   * wave w = (out-feature tile ot = w >> 1, k-step s = w & 1) builds ITS A fragments in registers (G2 rebuilt from gz
+//     and the layer-2 sign bits as in shade.hip, G1 from the tile) and ONE of the 8 shared B fragments of H1 (+ the two of
+//     X by waves 0 / 1), which travel through LDS to the waves that need them: nothing is split twice;
+//   * 4 in-feature tiles + the X tile = 30 MFMAs per wave and tile; dW3, the <= 8 trailing columns of dW1 and the bias
+//     sums are fp32 VALU on the unsplit values;
+//   * the two k-step halves of an output tile are added through LDS once, at the end of the kernel.
+// ----------------------------------------------------------------------------------
+template <int WIDTH>
+struct X3WgradLds {
+  static constexpr int T = WIDTH / 32;
+  float g1[2][32][WIDTH], h1[2][32][WIDTH], h2[2][32][WIDTH];
+  float x[2][32][40];
+  float gz[2][32][4];
+  unsigned int m2[2][32][2][2];            // layer-2 sign bits [row][lane half of the forward][32-bit half]
+  u32x4 fb[T + 1][2][3][64];               // shared B fragments: [in tile (T = the X tile)][k-step][piece][lane]
+};
+
+typedef const __attribute__((address_space(1))) void* x3_gptr_t;
+typedef __attribute__((address_space(3))) void* x3_lptr_t;
+
+template <int WIDTH>
+__global__ void __launch_bounds__(WIDTH * 4)          // 2 * T waves: 512 threads for width 128, 256 for 64
+shade_wgrad_x3_kernel(const float* __restrict__ G1, const float* __restrict__ gz, const unsigned int* __restrict__ masks,
+                      const float* __restrict__ W3, const float* __restrict__ H1, const float* __restrict__ H2,
+                      const float* __restrict__ feat, int C, int c_view0, int n_view, const float* __restrict__ emb, int E,
+                      const int64_t* __restrict__ ray_id, int64_t M_cap, const int64_t* __restrict__ m_dev,
+                      float* __restrict__ part /* [gridDim][WIDTH*WIDTH + WIDTH*64 + 32*WIDTH + 3*WIDTH] */) {
+  const int64_t M = m_dev ? (*m_dev < M_cap ? *m_dev : M_cap) : M_cap;      // sample count kept on the device (train.py)
+  constexpr int T = WIDTH / 32;
+  constexpr int NW = 2 * T;                  // waves
+  constexpr int NT = NW * 64;                // threads
+  constexpr int TPR = NT / 32;               // staging threads per X row
+  constexpr int NXI = 40 / TPR > 0 ? (40 + TPR - 1) / TPR : 1;    // X columns per staging thread
+  constexpr int LPR = WIDTH / 4;             // lanes per operand row in a DMA instruction (16 B per lane)
+  constexpr int RPI = 64 / LPR;              // rows per DMA wave instruction (1 KB)
+  constexpr int IPW = 32 / RPI / NW;         // DMA instructions per wave and operand
+  __shared__ __attribute__((aligned(16))) X3WgradLds<WIDTH> L;
+  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, i = lane & 31, w = tid >> 6;
+  const int ot = w >> 1, ks = w & 1;
+  f32x16 aW2[T], aW1;
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) aW2[t][r] = 0.0f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) aW1[r] = 0.0f;
+  float vW3[3] = {0.0f, 0.0f, 0.0f}, vW1[8];
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) vW1[kk] = 0.0f;
+  float sb1 = 0.0f, sb2 = 0.0f, gz_acc = 0.0f;
+  // this lane's out feature f = 32 ot + i of layer 2: its W3 column, and where its sign bit lives in the forward's
+  // accumulator-order masks (f = 32t + (r&3) + 8(r>>2) + 4h'  ->  word h', bit 16t + r)
+  const float w30 = W3[32 * ot + i], w31 = W3[WIDTH + 32 * ot + i], w32 = W3[2 * WIDTH + 32 * ot + i];
+  const int m_half = (i >> 2) & 1, m_word = ot >> 1, m_bit = 16 * (ot & 1) + (i & 3) + 4 * (i >> 3);
+  const int d_in = n_view + E;
+  const int64_t n_tiles = (M + 31) / 32;
+
+  float px[NXI], pgz;
+  unsigned int pm2;
+  bool pvalid, pgvalid;
+  const int xrow = tid / TPR, xcol = tid - xrow * TPR;
+  auto issue = [&](int64_t tile, int buf) {
+    const int64_t r0 = tile * 32;
+    {
+      const int64_t row = r0 + xrow;
+      const int64_t rc = row < M ? row : M - 1;
+      const float* fr = feat + rc * C + c_view0;
+      const float* er = emb + ray_id[rc] * E - n_view;
+#pragma unroll
+      for (int q = 0; q < NXI; ++q) {
+        const int k = xcol + TPR * q;
+        const int kc = k < d_in ? k : d_in - 1;
+        px[q] = *((kc < n_view) ? fr + kc : er + kc);
+      }
+      pvalid = row < M;
+    }
+    {
+      const int64_t row = r0 + ((tid & 127) >> 2);
+      const int64_t rc = row < M ? row : M - 1;
+      pgz = gz[rc * 3 + ((tid & 3) < 3 ? (tid & 3) : 0)];
+      pgvalid = (tid & 3) < 3 && row < M;
+      pm2 = masks[rc * 8 + 4 + (tid & 3)];
+    }
+#pragma unroll
+    for (int q = 0; q < IPW; ++q) {
+      const int rl = (IPW * w + q) * RPI;
+      const int64_t row = r0 + rl + lane / LPR;
+      const int64_t off = (row < M ? row : M - 1) * WIDTH + 4 * (lane % LPR);
+      __builtin_amdgcn_global_load_lds((x3_gptr_t)(G1 + off), (x3_lptr_t)&L.g1[buf][rl][0], 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((x3_gptr_t)(H1 + off), (x3_lptr_t)&L.h1[buf][rl][0], 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((x3_gptr_t)(H2 + off), (x3_lptr_t)&L.h2[buf][rl][0], 16, 0, 0);
+    }
+  };
+
+  int buf = 0;
+  if ((int64_t)blockIdx.x < n_tiles) issue(blockIdx.x, 0);
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, buf ^= 1) {
+    // ---- the tile's small operands to LDS; its DMA has landed
+#pragma unroll
+    for (int q = 0; q < NXI; ++q) {
+      const int k = xcol + TPR * q;
+      if (k < 40) L.x[buf][xrow][k] = (pvalid && k < d_in) ? px[q] : 0.0f;
+    }
+    if (tid < 128) {
+      gz_acc += pgvalid ? pgz : 0.0f;                     // db3[c] = sum of gz[:, c]
+      L.gz[buf][tid >> 2][tid & 3] = pgvalid ? pgz : 0.0f;
+      (&L.m2[buf][tid >> 2][0][0])[tid & 3] = pm2;
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's share of the DMA has landed
+    __syncthreads();
+    if (tile + gridDim.x < n_tiles) issue(tile + gridDim.x, buf ^ 1);       // next tile: in flight under this one
+    const int rows_valid = (int)(M - tile * 32 < 32 ? M - tile * 32 : 32);  // wave-uniform
+    // ---- shared B fragments: wave w builds H1 (in tile w & (T-1), k-step w / T); waves 0 / 1 also the X tile's
+    {
+      const int bt = w & (T - 1), bs = w / T;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = L.h1[buf][16 * bs + 8 * h + e][32 * bt + i];     // rows past M: multiplied by a zero A
+      u32x4 p0, p1, p2;
+      x3_split8(v, p0, p1, p2);
+      L.fb[bt][bs][0][lane] = p0; L.fb[bt][bs][1][lane] = p1; L.fb[bt][bs][2][lane] = p2;
+      if (w < 2) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = L.x[buf][16 * w + 8 * h + e][i];
+        x3_split8(v, p0, p1, p2);
+        L.fb[T][w][0][lane] = p0; L.fb[T][w][1][lane] = p1; L.fb[T][w][2][lane] = p2;
+      }
+    }
+    // ---- this wave's A fragments (k-step ks): G2 rebuilt from gz and the sign bits, G1 from the tile; fp32 tails
+    u32x4 a2f[3], a1f[3];
+    {
+      float a2[8], a1[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int row = 16 * ks + 8 * h + e;
+        const float4 gzr = *reinterpret_cast<const float4*>(&L.gz[buf][row][0]);     // 0 on rows past M
+        const float g2v = fmaf(w32, gzr.z, fmaf(w31, gzr.y, w30 * gzr.x));
+        a2[e] = ((L.m2[buf][row][m_half][m_word] >> m_bit) & 1u) ? g2v : 0.0f;
+        a1[e] = row < rows_valid ? L.g1[buf][row][32 * ot + i] : 0.0f;            // rows past M hold a clamped copy
+        sb2 += a2[e]; sb1 += a1[e];
+        const float hv = L.h2[buf][row][32 * ot + i];
+        vW3[0] = fmaf(gzr.x, hv, vW3[0]); vW3[1] = fmaf(gzr.y, hv, vW3[1]); vW3[2] = fmaf(gzr.z, hv, vW3[2]);
+        const float4 xa = *reinterpret_cast<const float4*>(&L.x[buf][row][32]);     // zero past d_in
+        const float4 xb = *reinterpret_cast<const float4*>(&L.x[buf][row][36]);
+        vW1[0] = fmaf(a1[e], xa.x, vW1[0]); vW1[1] = fmaf(a1[e], xa.y, vW1[1]); vW1[2] = fmaf(a1[e], xa.z, vW1[2]);
+        vW1[3] = fmaf(a1[e], xa.w, vW1[3]); vW1[4] = fmaf(a1[e], xb.x, vW1[4]); vW1[5] = fmaf(a1[e], xb.y, vW1[5]);
+        vW1[6] = fmaf(a1[e], xb.z, vW1[6]); vW1[7] = fmaf(a1[e], xb.w, vW1[7]);
+        if (e & 1) __builtin_amdgcn_sched_barrier(0);     // two rows' worth of LDS reads in flight, not all eight
+      }
+      x3_split8(a2, a2f[0], a2f[1], a2f[2]);
+      x3_split8(a1, a1f[0], a1f[1], a1f[2]);
+    }
+    __syncthreads();                        // the B fragments are complete
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      x3_mfma6(aW2[t], a2f[0], a2f[1], a2f[2], L.fb[t][ks][0][lane], L.fb[t][ks][1][lane], L.fb[t][ks][2][lane]);
+      __builtin_amdgcn_sched_barrier(0);      // one fragment triple in registers at a time
+    }
+    x3_mfma6(aW1, a1f[0], a1f[1], a1f[2], L.fb[T][ks][0][lane], L.fb[T][ks][1][lane], L.fb[T][ks][2][lane]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __syncthreads();
+  // ---- the two k-step halves of each output tile meet in LDS (reusing the operand buffers), then the record
+  float* red = &L.g1[0][0][0];              // (T + 1) * 16 * 64 floats per out tile: 80 KB at width 128 (g1, h1, h2 are contiguous)
+  if (ks == 1) {
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[((ot * (T + 1) + t) * 16 + r) * 64 + lane] = aW2[t][r];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[((ot * (T + 1) + T) * 16 + r) * 64 + lane] = aW1[r];
+  }
+  static_assert((T * (T + 1) * 16 * 64 + T * 14 * 64) * 4 <= 3 * 2 * 32 * WIDTH * 4, "the exchange fits the operand buffers");
+  float* red2 = red + T * (T + 1) * 16 * 64;   // the VALU sums of the ks == 1 waves: 14 floats per lane, behind `red`
+  if (ks == 1) {
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) red2[(ot * 14 + kk) * 64 + lane] = vW1[kk];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) red2[(ot * 14 + 8 + c) * 64 + lane] = vW3[c];
+    red2[(ot * 14 + 11) * 64 + lane] = sb1;
+    red2[(ot * 14 + 12) * 64 + lane] = sb2;
+  }
+  __syncthreads();
+  float* p = part + (int64_t)blockIdx.x * (WIDTH * WIDTH + WIDTH * 64 + 32 * WIDTH + 3 * WIDTH);
+  float* pW2 = p;                          // [WIDTH out][WIDTH in]
+  float* pW1 = pW2 + WIDTH * WIDTH;        // [WIDTH out][64]
+  float* pW3 = pW1 + WIDTH * 64;           // [32 (c padded)][WIDTH], rows 0..2 written
+  float* pb = pW3 + 32 * WIDTH;            // [3][WIDTH]: db1, db2, db3 (entries [0,3) + [8,11))
+  if (ks == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int oi = (r & 3) + 8 * (r >> 2) + 4 * h;       // D[row = out feature oi][col = in feature i]
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+        pW2[(32 * ot + oi) * WIDTH + 32 * t + i] = aW2[t][r] + red[((ot * (T + 1) + t) * 16 + r) * 64 + lane];
+      pW1[(32 * ot + oi) * 64 + i] = aW1[r] + red[((ot * (T + 1) + T) * 16 + r) * 64 + lane];
+    }
+    // VALU parts: this lane's out feature is 32 ot + i; lane halves and the partner wave hold other rows
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      float v = vW1[kk] + red2[(ot * 14 + kk) * 64 + lane];
+      v += __shfl_xor(v, 32);
+      if (h == 0) pW1[(32 * ot + i) * 64 + 32 + kk] = v;
+    }
+    if (h == 0) {
+#pragma unroll
+      for (int kk = 8; kk < 32; ++kk) pW1[(32 * ot + i) * 64 + 32 + kk] = 0.0f;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float v = vW3[c] + red2[(ot * 14 + 8 + c) * 64 + lane];
+      v += __shfl_xor(v, 32);
+      if (h == 0) pW3[c * WIDTH + 32 * ot + i] = v;
+    }
+    float s1 = sb1 + red2[(ot * 14 + 11) * 64 + lane], s2 = sb2 + red2[(ot * 14 + 12) * 64 + lane];
+    s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+    if (h == 0) { pb[32 * ot + i] = s1; pb[WIDTH + 32 * ot + i] = s2; }
+  }
+  // db3[c]: the staging threads 4*row + c (tid < 128: waves 0 and 1) hold per-row sums; fold the row bits of the lane
+  float gz_sum = gz_acc;
+  gz_sum += __shfl_xor(gz_sum, 4); gz_sum += __shfl_xor(gz_sum, 8);
+  gz_sum += __shfl_xor(gz_sum, 16); gz_sum += __shfl_xor(gz_sum, 32);
+  // record layout shared with shade.hip: db3 = entries [0,3) + [8,11) of the third bias row, everything else there zero
+  if (w < 2 && lane < 3) pb[2 * WIDTH + 8 * w + lane] = gz_sum;
+  for (int q = tid; q < WIDTH; q += NT)
+    if (q >= 16 || (q & 7) >= 3) pb[2 * WIDTH + q] = 0.0f;
+}
+
 extern "C" {
 
 // bytes of scratch the bf16 variants need per call (the weight image of the larger of the two kernels)
@@ -440,7 +680,7 @@ int64_t dvgo_shade_scratch_bytes(int width) {
   return 0;
 }
 
-int dvgo_shade_fwd_x3(const float* feat, int C, const float* emb, int E, const int64_t* ray_id, int64_t M,
+int dvgo_shade_fwd_x3(const float* feat, int C, const float* emb, int E, const int64_t* ray_id, int64_t M, const int64_t* m_dev,
                       const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
                       const float* b3, int width, int d_in, int diffuse, float* rgb, float* H1, float* H2,
                       uint64_t* masks, void* scratch, int experiment, void* stream) {
@@ -459,7 +699,7 @@ int dvgo_shade_fwd_x3(const float* feat, int C, const float* emb, int E, const i
 #define DVGO_SHADE_X3(W, KS, DIFF)                                                                                       \
   do {                                                                                                                   \
     x3_prep_fwd_kernel<W, KS><<<32, 256, 0, s>>>((X3Img<W, KS>*)scratch, W1, b1, W2, b2, W3, b3, d_in);                \
-    shade_fwd_x3_kernel<W, KS, DIFF><<<blocks, X3_THREADS, 0, s>>>(feat, C, c_view0, n_view, emb, E, ray_id, M, scratch, rgb, \
+    shade_fwd_x3_kernel<W, KS, DIFF><<<blocks, X3_THREADS, 0, s>>>(feat, C, c_view0, n_view, emb, E, ray_id, M, m_dev, scratch, rgb, \
                                                                     H1, H2, (unsigned long long*)masks, experiment);     \
   } while (0)
   if (width == 128) {
@@ -473,7 +713,7 @@ int dvgo_shade_fwd_x3(const float* feat, int C, const float* emb, int E, const i
   return 0;
 }
 
-int dvgo_shade_bwd_x3(const float* g_rgb, const float* rgb, const uint64_t* masks, int64_t M,
+int dvgo_shade_bwd_x3(const float* g_rgb, const float* rgb, const uint64_t* masks, int64_t M, const int64_t* m_dev,
                       const float* W1, const float* W2, const float* W3, int width, int d_in, int C, int diffuse,
                       float* g_feat, float* G1, float* gz, void* scratch, void* stream) {
   if (M < 0 || C <= 0) return DVGO_EINVAL;
@@ -489,12 +729,30 @@ int dvgo_shade_bwd_x3(const float* g_rgb, const float* rgb, const uint64_t* mask
 #define DVGO_SHADE_BWD_X3(W, DIFF)                                                                                        \
   do {                                                                                                                    \
     x3_prep_bwd_kernel<W><<<32, 256, 0, s>>>((X3BwdImg<W>*)scratch, W1, W2, W3, d_in);                                  \
-    shade_bwd_x3_kernel<W, DIFF><<<blocks, X3_THREADS, 0, s>>>(g_rgb, rgb, (const unsigned long long*)masks, M, scratch, C, \
+    shade_bwd_x3_kernel<W, DIFF><<<blocks, X3_THREADS, 0, s>>>(g_rgb, rgb, (const unsigned long long*)masks, M, m_dev, scratch, C, \
                                                                 c_view0, n_view, g_feat, G1, gz);                         \
   } while (0)
   if (width == 128) { if (diffuse) DVGO_SHADE_BWD_X3(128, true); else DVGO_SHADE_BWD_X3(128, false); }
   else              { if (diffuse) DVGO_SHADE_BWD_X3(64, true); else DVGO_SHADE_BWD_X3(64, false); }
 #undef DVGO_SHADE_BWD_X3
+  DVGO_LAUNCH_CHECK();
+  return 0;
+}
+
+int dvgo_shade_wgrad_x3(const float* G1, const float* gz, const uint64_t* masks, const float* W3, const float* H1,
+                        const float* H2, const float* feat, int C, const float* emb, int E, const int64_t* ray_id, int64_t M,
+                        const int64_t* m_dev, int width, int diffuse, int n_parts, float* part, void* stream) {
+  if (M < 0 || n_parts <= 0 || C <= 0 || E < 0) return DVGO_EINVAL;
+  if (!G1 || !gz || !masks || !W3 || !H1 || !H2 || !feat || !emb || !ray_id || !part) return DVGO_EINVAL;
+  const int c_view0 = diffuse ? 3 : 0;
+  const int n_view = C - c_view0;
+  if ((width != 128 && width != 64) || n_view < 0 || n_view + E > 40) return DVGO_ERANGE;
+  if (width == 128)
+    shade_wgrad_x3_kernel<128><<<n_parts, 512, 0, (hipStream_t)stream>>>(G1, gz, (const unsigned int*)masks, W3, H1, H2, feat, C,
+                                                                         c_view0, n_view, emb, E, ray_id, M, m_dev, part);
+  else
+    shade_wgrad_x3_kernel<64><<<n_parts, 256, 0, (hipStream_t)stream>>>(G1, gz, (const unsigned int*)masks, W3, H1, H2, feat, C,
+                                                                        c_view0, n_view, emb, E, ray_id, M, m_dev, part);
   DVGO_LAUNCH_CHECK();
   return 0;
 }

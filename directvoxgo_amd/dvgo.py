@@ -296,7 +296,7 @@ class DirectVoxGO(nn.Module):
         return ray_pts[mask_inbbox], ray_id[mask_inbbox], step_id[mask_inbbox]
 
     # ------------------------------------------------------------------ colour head
-    def _shade(self, k0, viewdirs, ray_id):
+    def _shade(self, k0, viewdirs, ray_id, m_dev=None):
         """lib/dvgo.py:512-541 (bilinear / non-implicit branches)."""
         if self.rgbnet is None:
             return torch.sigmoid(k0)
@@ -306,9 +306,11 @@ class DirectVoxGO(nn.Module):
             k0_view = k0[:, 3:]
             k0_diffuse = k0[:, :3]
         if self.fused and self.fused_shade and viewdirs.is_cuda and viewdirs.dim() == 2:
-            rgb = shade(self.rgbnet, k0, viewdir_embed(viewdirs, self.viewfreq), ray_id, diffuse=not self.rgbnet_direct)
+            rgb = shade(self.rgbnet, k0, viewdir_embed(viewdirs, self.viewfreq), ray_id, diffuse=not self.rgbnet_direct,
+                        m_dev=m_dev)
             if rgb is not None:
                 return rgb
+        assert m_dev is None, 'capacity mode needs the fused colour head'      # (torch ops would run over undefined rows)
         viewdirs_emb = (viewdirs.unsqueeze(-1) * self.viewfreq).flatten(-2)
         viewdirs_emb = torch.cat([viewdirs, viewdirs_emb.sin(), viewdirs_emb.cos()], -1)
         viewdirs_emb = viewdirs_emb.flatten(0, -2)[ray_id]
@@ -341,15 +343,28 @@ class DirectVoxGO(nn.Module):
             return self._forward_fused(rays_o, rays_d, viewdirs, **render_kwargs)
         return self._forward_unfused(rays_o, rays_d, viewdirs, global_step, **render_kwargs)
 
-    def _forward_fused(self, rays_o, rays_d, viewdirs, near, far, stepsize, bg, render_depth=False, **_unused):
+    def can_keep_count_on_device(self):
+        """True when `forward(..., _capacity=True)` is available: the fused march with the fused colour head."""
+        from .shade import head_layers
+        return bool(self.fused and self.fused_shade and self.rgbnet is not None and head_layers(self.rgbnet) is not None)
+
+    def _forward_fused(self, rays_o, rays_d, viewdirs, near, far, stepsize, bg, render_depth=False, _capacity=False,
+                       **_unused):
+        """`_capacity` (training step only, train.py): no host synchronisation -- the per-sample outputs are allocated at
+        their upper bound, only their first `ret['n_samples']` rows (a device scalar) are defined, and every kernel
+        downstream reads that count from the device."""
         N = len(rays_o)
         cfg = self._march_cfg(near, far, stepsize)
+        _capacity = bool(_capacity) and self.can_keep_count_on_device() and viewdirs.is_cuda and viewdirs.dim() == 2
         weights, alpha, alphainv_last, k0, ray_id, step_id, off3 = fused_march(
-            self.density, self.k0, rays_o, rays_d, cfg)
-        rgb = self._shade(k0, viewdirs, ray_id)
-        rgb_marched = composite(weights, rgb, alphainv_last, ray_id, off3, bg)
+            self.density, self.k0, rays_o, rays_d, cfg, capacity=_capacity)
+        m_dev = off3[N:] if _capacity else None
+        rgb = self._shade(k0, viewdirs, ray_id, m_dev)
+        rgb_marched = composite(weights, rgb, alphainv_last, ray_id, off3, bg, m_dev)
         ret = {'alphainv_last': alphainv_last, 'weights': weights, 'rgb_marched': rgb_marched,
                'raw_alpha': alpha, 'raw_rgb': rgb, 'ray_id': ray_id}
+        if _capacity:
+            ret['n_samples'] = m_dev
         if render_depth:
             ret['depth'] = composite_depth(weights.detach(), step_id, off3, N)
         return ret

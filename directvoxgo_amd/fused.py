@@ -108,7 +108,7 @@ def split_grid_rows(G, density, k0):
 
 class _FusedMarch(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, density, k0, rays_o, rays_d, cfg):
+    def forward(ctx, density, k0, rays_o, rays_d, cfg, capacity=False):
         for x, n in ((rays_o, 'rays_o'), (rays_d, 'rays_d')):
             check_input(x, n); check_f32(x, n)
         if not (density.is_cuda and k0.is_cuda):
@@ -174,7 +174,13 @@ class _FusedMarch(torch.autograd.Function):
                 L.call('dvgo_exclusive_scan_i32', ptr(n3), _i64(N), ptr(off3), st)
                 if bricks:
                     L.call('dvgo_brick_scan', ptr(brick_cnt), _int(nb), ptr(brick_off), ptr(brick_cur), st)
-            if bricks:
+            if capacity and stride > 0 and bricks:
+                # training step (train.py): the surviving-sample count stays on the device.  The outputs are sized by
+                # their upper bound -- every step of every ray -- and every consumer is handed off3[N] as a device
+                # pointer (`m_dev`): no host synchronisation in the forward at all.  Rows past the count are garbage.
+                M3 = stride * N
+                n_entries = 8 * M3                              # a sample touches at most 2 x 2 x 2 bricks
+            elif bricks:
                 M3, n_entries = torch.stack((off3[-1], brick_off[-1].long())).tolist()   # the one host sync
             else:
                 M3 = int(off3[-1].item())                      # the one host sync of the fused forward
@@ -190,6 +196,7 @@ class _FusedMarch(torch.autograd.Function):
         ctx.cfg = cfg
         ctx.geom = (X, Y, Z, C, sC, sX, sY, sZ, stride, N)
         ctx.bricks = (brick_off, brick_cur, n_entries) if bricks else None
+        ctx.padded = bool(capacity and stride > 0 and bricks)
         ctx.density_meta, ctx.k0_meta = density, k0
         ctx.save_for_backward(rec2, n2, n_steps, cum if cum is not None else n_steps, off3, start, dirs, last,
                               ray_id, step_id)
@@ -222,6 +229,8 @@ class _FusedMarch(torch.autograd.Function):
                        _flt(cfg.interval), ptr(gw), ptr(gl), _int(X), _int(Y), _int(Z), ptr(dst), _i64(dst_stride),
                        ptr(kept), ptr(cursor), ptr(recs), st)
 
+            if ctx.padded and not (ctx.bricks is not None and want_k0 and want_d and BRICK_SCATTER):
+                raise RuntimeError('capacity-mode forward (device-side sample count) needs the brick scatter backward for both grids')
             if ctx.bricks is not None and want_k0 and want_d and BRICK_SCATTER:
                 # owner-computes scatter: list every sample per brick, then one workgroup sums each brick
                 brick_off, brick_cur, E = ctx.bricks
@@ -238,15 +247,15 @@ class _FusedMarch(torch.autograd.Function):
                            cfg.xyz_min_h, cfg.xyz_max_h, ptr(g_feat), _int(C), _int(X), _int(Y), _int(Z), ptr(None), ptr(None),
                            *tail, st)
                     cap.stepped = True
-                    return None, None, None, None, None
+                    return None, None, None, None, None, None
                 grad_k0 = torch.empty_like(ctx.k0_meta, memory_format=torch.preserve_format)
                 grad_density = torch.empty_like(ctx.density_meta)
                 assert grad_k0.stride() == ctx.k0_meta.stride() and grad_density.is_contiguous()
                 L.call('dvgo_brick_accumulate', ptr(brick_off), ptr(recs), ptr(start), ptr(dirs), _flt(cfg.stepdist),
                        cfg.xyz_min_h, cfg.xyz_max_h, ptr(g_feat), _int(C), _int(X), _int(Y), _int(Z), ptr(grad_k0),
                        ptr(grad_density), ptr(None), ptr(None), ptr(None), _flt(0), _int(0),
-                       ptr(None), ptr(None), ptr(None), _flt(0), _int(0), _flt(0), _flt(0), _flt(0), st)
-                return grad_density, grad_k0, None, None, None
+                       ptr(None), ptr(None), ptr(None), _flt(0), _int(0), _flt(0), _flt(0), _flt(0), ptr(None), st)
+                return grad_density, grad_k0, None, None, None, None
 
             # worth its two extra full-grid passes (zero 64 B, split 116 B per voxel) from ~1 kept sample per 6 voxels
             combined = (COMBINED_GRID_GRAD and want_k0 and want_d and C == 12 and M3 * COMBINED_MIN_RATIO >= X * Y * Z and tuple(ctx.density_meta.shape[2:]) == (X, Y, Z)
@@ -263,7 +272,7 @@ class _FusedMarch(torch.autograd.Function):
                 cap = grid_rows_capture._active
                 if cap is not None and cap.G is None and cap.density is ctx.density_meta and cap.k0 is ctx.k0_meta:
                     cap.G = G                  # the optimizer consumes the rows; no dense gradients are produced
-                    return None, None, None, None, None
+                    return None, None, None, None, None, None
                 grad_k0 = torch.empty_like(ctx.k0_meta, memory_format=torch.preserve_format)
                 grad_density = torch.empty_like(ctx.density_meta)
                 assert grad_k0.stride() == ctx.k0_meta.stride() and grad_density.is_contiguous()
@@ -279,7 +288,7 @@ class _FusedMarch(torch.autograd.Function):
                 if want_d:
                     grad_density = torch.zeros_like(ctx.density_meta)
                     density_bwd(grad_density, 1, None)
-        return grad_density, grad_k0, None, None, None
+        return grad_density, grad_k0, None, None, None, None
 
 
 @torch.no_grad()
@@ -308,15 +317,17 @@ def fused_hit(rays_o, rays_d, cfg):
     return hit
 
 
-def fused_march(density, k0, rays_o, rays_d, cfg):
+def fused_march(density, k0, rays_o, rays_d, cfg, capacity=False):
     """-> weights [M3], raw_alpha [M3], alphainv_last [N], k0 features [M3,C], ray_id, step_id [M3],
-    off3 [N+1] (exclusive offsets of each ray's samples in the M3 arrays)."""
-    return _FusedMarch.apply(density, k0, rays_o.contiguous(), rays_d.contiguous(), cfg)
+    off3 [N+1] (exclusive offsets of each ray's samples in the M3 arrays).
+    `capacity=True`: no host synchronisation; the M3-sized outputs are allocated at their upper bound and only their
+    first off3[N] rows are defined (pass `off3[N:]` as `m_dev` to the consumers)."""
+    return _FusedMarch.apply(density, k0, rays_o.contiguous(), rays_d.contiguous(), cfg, capacity)
 
 
 class _Composite(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, weights, rgb, alphainv_last, ray_id, off3, bg):
+    def forward(ctx, weights, rgb, alphainv_last, ray_id, off3, bg, m_dev=None):
         N = alphainv_last.shape[0]
         rgb = rgb.contiguous()
         weights = weights.contiguous()
@@ -327,6 +338,7 @@ class _Composite(torch.autograd.Function):
         ctx.save_for_backward(weights, rgb, ray_id)
         ctx.bg = float(bg)
         ctx.N = N
+        ctx.m_dev = m_dev
         return out
 
     @staticmethod
@@ -339,14 +351,14 @@ class _Composite(torch.autograd.Function):
         grgb = torch.empty_like(rgb) if ctx.needs_input_grad[1] else None
         glast = torch.empty(ctx.N, dtype=torch.float32, device=g.device) if ctx.needs_input_grad[2] else None
         with L.device_of(weights):
-            L.call('dvgo_march_composite_bwd', ptr(g), ptr(weights), ptr(rgb), ptr(ray_id), _i64(M3), _i64(ctx.N),
+            L.call('dvgo_march_composite_bwd', ptr(g), ptr(weights), ptr(rgb), ptr(ray_id), _i64(M3), ptr(ctx.m_dev), _i64(ctx.N),
                    _flt(ctx.bg), ptr(gw), ptr(grgb), ptr(glast), stream_of(weights))
-        return gw, grgb, glast, None, None, None
+        return gw, grgb, glast, None, None, None, None
 
 
-def composite(weights, rgb, alphainv_last, ray_id, off3, bg):
+def composite(weights, rgb, alphainv_last, ray_id, off3, bg, m_dev=None):
     """rgb_marched = segment_sum(weights * rgb) + alphainv_last * bg   (lib/dvgo.py:554-559)"""
-    return _Composite.apply(weights, rgb, alphainv_last, ray_id, off3, bg)
+    return _Composite.apply(weights, rgb, alphainv_last, ray_id, off3, bg, m_dev)
 
 
 @torch.no_grad()

@@ -40,8 +40,9 @@ def adam_upd(param, grad, exp_avg, exp_avg_sq, step, beta1, beta2, lr, eps, mode
                stream_of(param))
 
 
-def adam_upd_multi(items, step, beta1, beta2, lr, eps):
-    """Plain Adam over up to 16 small (param, state) pairs in one launch (csrc/loss.hip)."""
+def adam_upd_multi(items, step, beta1, beta2, lr, eps, step_size_dev=None):
+    """Plain Adam over up to 16 small (param, state) pairs in one launch (csrc/loss.hip).  `step_size_dev`: a 1-element
+    device float tensor holding the step size (captured steps), read instead of the host value."""
     import ctypes
     n = len(items)
     PT = ctypes.c_void_p * n
@@ -53,7 +54,7 @@ def adam_upd_multi(items, step, beta1, beta2, lr, eps):
     p0 = items[0][0]
     with L.device_of(p0):
         L.call('dvgo_adam_upd_multi', ps, gs, ms, vs, ne, _int(n), _flt(adam_step_size(lr, beta1, beta2, step)), _flt(beta1),
-               _flt(beta2), _flt(eps), stream_of(p0))
+               _flt(beta2), _flt(eps), ptr(step_size_dev), stream_of(p0))
 
 
 class MaskedAdam(torch.optim.Optimizer):
@@ -67,6 +68,10 @@ class MaskedAdam(torch.optim.Optimizer):
             if not ok:
                 raise ValueError(f'Invalid {name}: {val}')
         self.per_lr = None
+        # captured training steps (train.TrainStep.capture): the bias-corrected step sizes live in this device tensor
+        # ([0] feature grid, [1] density grid, [2 + g] small tensors of param group g) and the kernels read them from
+        # there, so that a replayed HIP graph sees the values of ITS step; `hyper_begin` fills it
+        self.hyper_dev, self._hyper_pin = None, None
         super().__init__(params, {'lr': lr, 'betas': betas, 'eps': eps})
 
     def set_pervoxel_lr(self, count):
@@ -135,6 +140,37 @@ class MaskedAdam(torch.optim.Optimizer):
                 self._state_of(p)
         return True
 
+    def hyper_begin(self, density, k0, advance=False):
+        """Step sizes of the NEXT optimizer step (state step + 1, current lr) -> device, ahead of the kernels that will
+        read them.  `advance=True` (graph replay: the captured Python does not run) also counts the step on the host."""
+        if self.hyper_dev is None:
+            self.hyper_dev = torch.zeros(2 + len(self.param_groups), dtype=torch.float32, device=k0.device)
+            # the host may run many replays ahead of the GPU: every upload gets its own pinned slot, recycled only after
+            # the copy that read it has executed
+            self._hyper_pin = [(torch.zeros(2 + len(self.param_groups), dtype=torch.float32).pin_memory(), torch.cuda.Event())
+                               for _ in range(64)]
+            self._hyper_next = 0
+        vals, done = self._hyper_pin[self._hyper_next]
+        self._hyper_next = (self._hyper_next + 1) % len(self._hyper_pin)
+        done.synchronize()
+        for slot, p in ((0, k0), (1, density)):
+            g, st = self._group_of(p), self._state_of(p)
+            vals[slot] = adam_step_size(g['lr'], g['betas'][0], g['betas'][1], st['step'] + 1)
+            if advance:
+                st['step'] += 1
+        for gi, g in enumerate(self.param_groups):
+            steps = {self._state_of(p)['step'] for p in g['params'] if p is not density and p is not k0 and p.requires_grad}
+            if len(steps) > 1:
+                raise RuntimeError('captured steps need one step count per param group')
+            if steps:
+                vals[2 + gi] = adam_step_size(g['lr'], g['betas'][0], g['betas'][1], steps.pop() + 1)
+                if advance:
+                    for p in g['params']:
+                        if p is not density and p is not k0 and p.requires_grad:
+                            self._state_of(p)['step'] += 1
+        self.hyper_dev.copy_(vals, non_blocking=True)
+        done.record()
+
     def grid_step_args(self, density, k0):
         """Counts one step for both grids and returns the Adam argument tail of dvgo_brick_accumulate
         (csrc/brick.hip): the update `step()` would make, applied by the scatter kernel from its LDS tile."""
@@ -146,7 +182,8 @@ class MaskedAdam(torch.optim.Optimizer):
         return (ptr(k0), ptr(sk['exp_avg']), ptr(sk['exp_avg_sq']), _flt(adam_step_size(gk['lr'], b1, b2, sk['step'])),
                 _int(1 if gk.get('skip_zero_grad', False) else 0),
                 ptr(density), ptr(sd['exp_avg']), ptr(sd['exp_avg_sq']), _flt(adam_step_size(gd['lr'], b1, b2, sd['step'])),
-                _int(1 if gd.get('skip_zero_grad', False) else 0), _flt(b1), _flt(b2), _flt(gk['eps']))
+                _int(1 if gd.get('skip_zero_grad', False) else 0), _flt(b1), _flt(b2), _flt(gk['eps']),
+                ptr(self.hyper_dev[0:2]) if self.hyper_dev is not None else ptr(None))
 
     @torch.no_grad()
     def step_grid_rows(self, density, k0, G):
@@ -210,6 +247,8 @@ class MaskedAdam(torch.optim.Optimizer):
             by_step = {}
             for p, st in small:
                 by_step.setdefault(st['step'], []).append((p, st))
+            gi = next(i for i, g in enumerate(self.param_groups) if g is group)
             for stp, items in by_step.items():
                 for i in range(0, len(items), 16):
-                    adam_upd_multi(items[i:i + 16], stp, b1, b2, group['lr'], group['eps'])
+                    adam_upd_multi(items[i:i + 16], stp, b1, b2, group['lr'], group['eps'],
+                                   self.hyper_dev[2 + gi:3 + gi] if self.hyper_dev is not None else None)

@@ -109,7 +109,7 @@ def _scratch(width, device):
 
 class _Shade(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, feat, emb, ray_id, W1, b1, W2, b2, W3, b3, diffuse, train):
+    def forward(ctx, feat, emb, ray_id, W1, b1, W2, b2, W3, b3, diffuse, train, m_dev):
         M, C = feat.shape
         E = emb.shape[1]
         width, d_in = W1.shape
@@ -123,13 +123,14 @@ class _Shade(torch.autograd.Function):
         masks = torch.empty((M, 4), dtype=torch.int64, device=feat.device) if train else None
         scratch = _scratch(width, feat.device)
         with L.device_of(feat):
-            L.call('dvgo_shade_fwd', ptr(feat), _int(C), ptr(emb), _int(E), ptr(ray_id), _i64(M), ptr(W1.contiguous()),
+            L.call('dvgo_shade_fwd', ptr(feat), _int(C), ptr(emb), _int(E), ptr(ray_id), _i64(M), ptr(m_dev), ptr(W1.contiguous()),
                    ptr(b1.contiguous()), ptr(W2.contiguous()), ptr(b2.contiguous()), ptr(W3.contiguous()),
                    ptr(b3.contiguous()), _int(width), _int(d_in), _int(1 if diffuse else 0), ptr(rgb), ptr(H1), ptr(H2),
                    ptr(masks), ptr(scratch), stream_of(feat))
         if train:
             ctx.save_for_backward(feat, emb, ray_id, W1, W2, W3, rgb, H1, H2, masks)
             ctx.diffuse = diffuse
+            ctx.m_dev = m_dev            # None, or the device-side sample count (arrays are then capacity-sized)
             ctx.params = (W1, b1, W2, b2, W3, b3)
         return rgb
 
@@ -137,7 +138,7 @@ class _Shade(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_rgb):
         feat, emb, ray_id, W1, W2, W3, rgb, H1, H2, masks = ctx.saved_tensors
-        diffuse = ctx.diffuse
+        diffuse, m_dev = ctx.diffuse, ctx.m_dev
         M, C = feat.shape
         width, d_in = W1.shape
         g_feat = torch.empty_like(feat)
@@ -145,7 +146,7 @@ class _Shade(torch.autograd.Function):
         gz = torch.empty_like(rgb)
         scratch = _scratch(width, feat.device)
         with L.device_of(feat):
-            L.call('dvgo_shade_bwd', ptr(g_rgb.contiguous()), ptr(rgb), ptr(masks), _i64(M), ptr(W1.contiguous()),
+            L.call('dvgo_shade_bwd', ptr(g_rgb.contiguous()), ptr(rgb), ptr(masks), _i64(M), ptr(m_dev), ptr(W1.contiguous()),
                    ptr(W2.contiguous()), ptr(W3.contiguous()), _int(width), _int(d_in), _int(C), _int(1 if diffuse else 0),
                    ptr(g_feat), ptr(G1), ptr(gz), ptr(scratch), stream_of(feat))
 
@@ -156,7 +157,7 @@ class _Shade(torch.autograd.Function):
             tot = torch.empty(psize, dtype=torch.float32, device=feat.device)
             with L.device_of(feat):
                 L.call('dvgo_shade_wgrad', ptr(G1), ptr(gz), ptr(masks), ptr(W3.contiguous()), ptr(H1), ptr(H2), ptr(feat), _int(C), ptr(emb),
-                       _int(emb.shape[1]), ptr(ray_id), _i64(M), _int(width), _int(1 if diffuse else 0), _int(n_parts),
+                       _int(emb.shape[1]), ptr(ray_id), _i64(M), ptr(m_dev), _int(width), _int(1 if diffuse else 0), _int(n_parts),
                        ptr(part), ptr(tot), stream_of(feat))
             o = 0
             gW2 = tot[o:o + width * width].view(width, width); o += width * width
@@ -169,14 +170,16 @@ class _Shade(torch.autograd.Function):
         gf = g_feat if ctx.needs_input_grad[0] else None
         if defer_wgrad._active is not None:
             defer_wgrad._active.submit(ctx.params, wgrad, feat.device)
-            return (gf, None, None, None, None, None, None, None, None, None, None)
+            return (gf, None, None, None, None, None, None, None, None, None, None, None)
         gW1, gb1, gW2, gb2, gW3, gb3 = wgrad()
-        return (gf, None, None, gW1, gb1, gW2, gb2, gW3, gb3, None, None)
+        return (gf, None, None, gW1, gb1, gW2, gb2, gW3, gb3, None, None, None)
 
 
-def shade(rgbnet, feat, emb, ray_id, diffuse):
+def shade(rgbnet, feat, emb, ray_id, diffuse, m_dev=None):
     """rgb [M,3] = sigmoid(rgbnet(cat([feat[:,3:] if diffuse else feat, emb[ray_id]])) + (feat[:,:3] if diffuse)),
-    or None when the head is not the shape the kernel was built for."""
+    or None when the head is not the shape the kernel was built for.
+    `m_dev`: device-side sample count when the arrays are capacity-sized (fused.py `capacity` mode): rows past it are
+    neither read nor written."""
     layers = head_layers(rgbnet)
     if layers is None or not feat.is_cuda:
         return None
@@ -185,4 +188,4 @@ def shade(rgbnet, feat, emb, ray_id, diffuse):
     if l1.in_features != feat.shape[1] - c0 + emb.shape[1]:
         return None
     return _Shade.apply(feat, emb, ray_id, l1.weight, l1.bias, l2.weight, l2.bias, l3.weight, l3.bias, diffuse,
-                        torch.is_grad_enabled())
+                        torch.is_grad_enabled(), m_dev)

@@ -88,7 +88,7 @@ class _FusedLoss(torch.autograd.Function):
     unit_grad = False        # set by TrainStep around its own loss.backward() (saves three scaling launches)
 
     @staticmethod
-    def forward(ctx, rgb_marched, alphainv_last, raw_rgb, weights, ray_id, target, n_global, w_main, w_ent, w_per):
+    def forward(ctx, rgb_marched, alphainv_last, raw_rgb, weights, ray_id, target, n_global, w_main, w_ent, w_per, m_dev=None):
         from . import _lib as L
         from ._lib import _flt, _i64, ptr, stream_of
         N, M = rgb_marched.shape[0], raw_rgb.shape[0]
@@ -100,7 +100,7 @@ class _FusedLoss(torch.autograd.Function):
         loss = torch.empty((), dtype=torch.float32, device=dev)
         with L.device_of(rgb_marched):
             L.call('dvgo_loss_fwd_bwd', ptr(rgb_marched), ptr(alphainv_last), ptr(target.contiguous()), _i64(N), ptr(raw_rgb),
-                   ptr(weights.contiguous()), ptr(ray_id), _i64(M), _i64(int(n_global)), _flt(w_main), _flt(w_ent),
+                   ptr(weights.contiguous()), ptr(ray_id), _i64(M), ptr(m_dev), _i64(int(n_global)), _flt(w_main), _flt(w_ent),
                    _flt(w_per), ptr(g_marched), ptr(g_last), ptr(g_raw), ptr(loss), stream_of(rgb_marched))
         ctx.save_for_backward(g_marched, g_last, g_raw if g_raw is not None else g_last)
         ctx.has_raw = g_raw is not None
@@ -111,9 +111,9 @@ class _FusedLoss(torch.autograd.Function):
     def backward(ctx, go):
         g_marched, g_last, g_raw = ctx.saved_tensors
         if _FusedLoss.unit_grad:         # TrainStep calls loss.backward() itself: d loss / d loss = 1, nothing to scale
-            return (g_marched, g_last, g_raw if ctx.has_raw else None, None, None, None, None, None, None, None)
+            return (g_marched, g_last, g_raw if ctx.has_raw else None, None, None, None, None, None, None, None, None)
         return (g_marched * go, g_last * go, (g_raw * go) if ctx.has_raw else None, None, None, None, None, None, None,
-                None)
+                None, None)
 
 
 def fused_render_loss(render_result, target, n_rays_global, cfg_train):
@@ -121,15 +121,22 @@ def fused_render_loss(render_result, target, n_rays_global, cfg_train):
     return _FusedLoss.apply(render_result['rgb_marched'], render_result['alphainv_last'], render_result['raw_rgb'],
                             render_result['weights'].detach(), render_result['ray_id'], target, n_rays_global,
                             float(cfg_train['weight_main']), float(cfg_train['weight_entropy_last']),
-                            float(cfg_train['weight_rgbper']))
+                            float(cfg_train['weight_rgbper']), render_result.get('n_samples'))
 
 
 class TrainStep:
     """One optimisation step on one batch of rays; ``world_size > 1`` shards the batch by rank."""
 
     def __init__(self, model, cfg_train, render_kwargs, optimizer=None, process_group=None, fused_loss=True,
-                 overlap_wgrad=True, touched_reduce=True, rows_adam=True, track_mse=False, shard_grids=True):
+                 overlap_wgrad=True, touched_reduce=True, rows_adam=True, track_mse=False, shard_grids=True, sync_free=False):
         self.model = model
+        # keep the count of surviving samples on the device (model.forward(_capacity=True)): no host synchronisation in
+        # the step.  That is what makes the step capturable (`capture()` switches it on); run eagerly it buys nothing --
+        # the sparse step is bound by host work, not by the one read -- and costs capacity-sized temporaries, so it is
+        # off by default
+        self.sync_free = sync_free
+        self._m3_seen = None                 # last sample count read back (asynchronously, a step or two late)
+        self._m3_pin, self._m3_event = None, None
         # data parallel, dense scenes: reduce-scatter the grid gradients, update only the owned slab, all-gather the
         # parameters (see _sharded_*); False = plain all-reduce + full update on every rank
         self.shard_grids = shard_grids
@@ -270,6 +277,22 @@ class TrainStep:
             works.append(dist.all_gather_into_tensor(fp, fp[lo:hi], group=self.pg, async_op=True))
         return works
 
+    def _sample_count(self, res):
+        """Number of surviving samples of the step, without waiting for it: exact when the forward read it back anyway,
+        else the last value that has arrived from the device (copied asynchronously into pinned memory every step)."""
+        n_dev = res.get('n_samples')
+        if n_dev is None:
+            return res['weights'].shape[0]
+        if self._m3_event is not None and self._m3_event.query():
+            self._m3_seen = int(self._m3_pin[0])
+        if self._m3_pin is None:
+            self._m3_pin = torch.empty(1, dtype=torch.int64).pin_memory()
+            self._m3_event = torch.cuda.Event()
+        if self._m3_event.query():                 # the previous copy has landed: start the next one
+            self._m3_pin.copy_(n_dev, non_blocking=True)
+            self._m3_event.record()
+        return self._m3_seen if self._m3_seen is not None else res['weights'].shape[0]
+
     def reduce_small(self):
         """One flat bucket for the handful of MLP gradients."""
         if self.world == 1:
@@ -284,11 +307,85 @@ class TrainStep:
                 p.grad.copy_(flat[off:off + n].view_as(p.grad))
                 off += n
 
-    def __call__(self, rays_o, rays_d, viewdirs, target, global_step):
-        """rays are this rank's shard; returns the (local share of the) loss as a 0-dim tensor."""
+    # ------------------------------------------------------------------------------------------------------------
+    # HIP-graph replay of the step.  A sparse-scene step is ~45 short kernels (0.55 ms of GPU work at 8192 rays on a
+    # lego-like scene) behind ~0.8 ms of host work (Python, allocator, launches): with the sample count kept on the device
+    # (`sync_free`) nothing in the step depends on a host read any more, so the whole of it -- forward, loss, backward,
+    # grid update inside the brick kernel, MLP Adam -- is captured once and replayed.  What changes from step to step
+    # travels through device memory: the batch (copied into the captured input tensors) and the bias-corrected Adam step
+    # sizes (`MaskedAdam.hyper_begin`).  Captured: one GPU, fused model + fused colour head, masked Adam on both grids,
+    # no total variation, fixed batch size and grid resolution; call `capture()` again after `scale_volume_grid` or an
+    # occupancy-mask refresh (both replace tensors the graph holds).
+    # ------------------------------------------------------------------------------------------------------------
+    def can_capture(self):
         cfg, model = self.cfg, self.model
+        density, k0 = getattr(model, 'density', None), getattr(model, 'k0', None)
+        tv = (cfg['weight_tv_density'] > 0 or cfg['weight_tv_k0'] > 0) and cfg['tv_before'] > cfg['tv_after']
+        return bool(self.world == 1 and self.fused_loss and self.rows_adam and not tv
+                    and isinstance(self.optimizer, MaskedAdam) and isinstance(density, nn.Parameter) and density.is_cuda
+                    and hasattr(model, 'can_keep_count_on_device') and model.can_keep_count_on_device()
+                    and self.optimizer.can_fuse_grid_step(density, k0) and self.optimizer.per_lr is None)
+
+    def capture(self, rays_o, rays_d, viewdirs, target, global_step=0, warmup=3):
+        """Run `warmup` eager steps on the given batch, then capture one step; later calls with a batch of the same size
+        replay it.  Returns False (and stays eager) when the step cannot be captured."""
+        self._graph = None
+        if not self.can_capture():
+            return False
+        model, opt = self.model, self.optimizer
+        self.sync_free = True                                      # from here on the sample count stays on the device
+        self._static = [t.detach().clone().contiguous() for t in (rays_o, rays_d, viewdirs, target)]
+        opt.hyper_begin(model.density, model.k0)                  # creates the device-side step sizes; eager steps use them too
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                              # (torch: warm up on a side stream before capturing)
+            for i in range(warmup):
+                self._eager(*self._static, global_step + i)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        # the capture pass runs the Python of one step without executing its kernels: put the host-side state back after
+        steps = {p: st['step'] for p, st in opt.state.items()}
+        lrs = [g['lr'] for g in opt.param_groups]
+        opt.hyper_begin(model.density, model.k0)
+        graph = torch.cuda.CUDAGraph()
+        self._capturing = True
+        try:
+            with torch.cuda.graph(graph):
+                self._static_loss = self._eager(*self._static, global_step + warmup)
+        finally:
+            self._capturing = False
+        for p, n in steps.items():
+            opt.state[p]['step'] = n
+        for g, lr in zip(opt.param_groups, lrs):
+            g['lr'] = lr
+        self._graph = graph
+        return True
+
+    def _replay(self, rays_o, rays_d, viewdirs, target):
+        for dst, src in zip(self._static, (rays_o, rays_d, viewdirs, target)):
+            dst.copy_(src, non_blocking=True)
+        self.optimizer.hyper_begin(self.model.density, self.model.k0, advance=True)    # this step's Adam step sizes
+        self._graph.replay()
+        for group in self.optimizer.param_groups:                                                  # run.py:401-406
+            group['lr'] = group['lr'] * self.decay_factor
+        return self._static_loss
+
+    def __call__(self, rays_o, rays_d, viewdirs, target, global_step):
+        """rays are this rank's shard; returns the (local share of the) loss as a 0-dim tensor (after `capture()`: a
+        tensor that the next call overwrites)."""
+        if getattr(self, '_graph', None) is not None and rays_o.shape == self._static[0].shape:
+            return self._replay(rays_o, rays_d, viewdirs, target)
+        return self._eager(rays_o, rays_d, viewdirs, target, global_step)
+
+    def _eager(self, rays_o, rays_d, viewdirs, target, global_step):
+        cfg, model = self.cfg, self.model
+        if isinstance(self.optimizer, MaskedAdam) and self.optimizer.hyper_dev is not None and not getattr(self, '_capturing', False):
+            self.optimizer.hyper_begin(model.density, model.k0)   # device-side step sizes of this step (see capture())
         n_global = rays_o.shape[0] * self.world
-        res = model(rays_o, rays_d, viewdirs, global_step=global_step, **self.render_kwargs)
+        keep_on_device = (self.sync_free and self.fused_loss and rays_o.is_cuda and hasattr(model, 'can_keep_count_on_device')
+                          and model.can_keep_count_on_device())
+        extra = {'_capacity': True} if keep_on_device else {}
+        res = model(rays_o, rays_d, viewdirs, global_step=global_step, **self.render_kwargs, **extra)
         self.optimizer.zero_grad(set_to_none=True)
         loss_fn = fused_render_loss if (self.fused_loss and res['rgb_marched'].is_cuda) else render_loss
         loss = loss_fn(res, target, n_global, cfg)
@@ -310,7 +407,11 @@ class TrainStep:
                 if use_rows else contextlib.nullcontext())
         # the second stream pays on kernel-bound steps (the weight-gradient kernel beside the grid scatter: -0.3 ms at
         # 2 M samples) and costs on launch-bound ones (stream switches and event records on the host: +0.1 ms at 0.2 M)
-        side = self.overlap_wgrad and self.world == 1 and res['weights'].shape[0] >= self.OVERLAP_MIN_SAMPLES
+        if getattr(self, '_capturing', False):       # no host reads while a graph is being captured: the last count seen
+            n_samples = self._m3_seen if self._m3_seen is not None else res['weights'].shape[0]
+        else:
+            n_samples = self._sample_count(res)
+        side = self.overlap_wgrad and self.world == 1 and n_samples >= self.OVERLAP_MIN_SAMPLES
         with defer_wgrad(side_stream=side) as deferred, rows as cap:
             _FusedLoss.unit_grad = True
             try:

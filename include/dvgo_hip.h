@@ -21,6 +21,10 @@
  *     a negative DVGO_E* code for invalid arguments.  Empty inputs (0 rays / 0 points)
  *     are valid everywhere and return 0 without launching.
  *   - outputs are caller-allocated; sizes are stated per function.
+ *   - `m_dev` (where an entry point has it, right after a sample count M): NULL, or a DEVICE pointer to the actual
+ *     sample count.  The kernels then process min(M, *m_dev) samples and M is only the capacity of the arrays: the
+ *     training step keeps the data-dependent count of surviving samples on the device and never reads it back
+ *     (train.py, fused.py `capacity` mode), which removes the forward's host synchronisation.
  */
 #ifndef DVGO_HIP_H
 #define DVGO_HIP_H
@@ -239,7 +243,7 @@ int dvgo_march_composite(const float* weights, const float* rgb /* [M3,3] */,
  *   grad_last (NULL or [n_rays]) = bg * sum_c g[r,c], the gradient w.r.t. alphainv_last (lib/dvgo.py:559),
  *   written by the same launch. */
 int dvgo_march_composite_bwd(const float* grad_rgb_marched /* [N,3] */, const float* weights,
-                             const float* rgb, const int64_t* ray_id, int64_t M3, int64_t n_rays,
+                             const float* rgb, const int64_t* ray_id, int64_t M3, const int64_t* m_dev, int64_t n_rays,
                              float bg, float* grad_weights /* [M3] */, float* grad_rgb /* [M3,3] */,
                              float* grad_last, void* stream);
 
@@ -308,7 +312,10 @@ int dvgo_brick_accumulate(const int32_t* brick_off, const void* recs, const floa
                           int C, int X, int Y, int Z, float* grad_k0, float* grad_density,
                           float* p_k0, float* m_k0, float* v_k0, float step_size_k0, int masked_k0,
                           float* p_density, float* m_density, float* v_density, float step_size_density,
-                          int masked_density, float beta1, float beta2, float eps, void* stream);
+                          int masked_density, float beta1, float beta2, float eps,
+                          const float* step_sizes_dev /* NULL, or device {step_size_k0, step_size_density}: read instead of
+                                                         the two float arguments (a captured step replays with new values) */,
+                          void* stream);
 
 /* Combined gradient rows G [n_vox][row_stride] (built by the two calls above) -> the channels-last feature
  * gradient [n_vox][C] and the density gradient [n_vox], both fully written.  Built for row_stride 16, C 12. */
@@ -344,7 +351,7 @@ int dvgo_maskout_near_cam(float* density, const float* grid_x, const float* grid
  * masks of dvgo_shade_bwd: 32 B per sample instead of re-reading 1 KB of activations).
  * Returns DVGO_ERANGE for shapes outside the built set (width == 128, d_in <= 40): fall back.
  * --------------------------------------------------------------------------------- */
-int dvgo_shade_fwd(const float* feat, int C, const float* emb, int E, const int64_t* ray_id, int64_t M,
+int dvgo_shade_fwd(const float* feat, int C, const float* emb, int E, const int64_t* ray_id, int64_t M, const int64_t* m_dev,
                    const float* W1, const float* b1, const float* W2, const float* b2,
                    const float* W3, const float* b3, int width, int d_in, int diffuse,
                    float* rgb, float* H1, float* H2, uint64_t* masks,
@@ -364,7 +371,7 @@ int dvgo_shade_variant(int flags);
  * G1 = relu'(H1) * (W2^T G2) as [M,width] where G2 = relu'(H2) * (W3^T gz) stays in registers (dvgo_shade_wgrad
  * rebuilds it from gz and the masks rather than streaming 512 B/sample), and g_feat [M,C] fully written:
  * channels [0,3) = gz when diffuse, channels [c0, C) = (W1^T G1)[:C-c0]. */
-int dvgo_shade_bwd(const float* g_rgb, const float* rgb, const uint64_t* masks, int64_t M,
+int dvgo_shade_bwd(const float* g_rgb, const float* rgb, const uint64_t* masks, int64_t M, const int64_t* m_dev,
                    const float* W1, const float* W2, const float* W3, int width, int d_in, int C, int diffuse,
                    float* g_feat, float* G1, float* gz, void* scratch, void* stream);
 
@@ -377,7 +384,7 @@ int dvgo_shade_bwd(const float* g_rgb, const float* rgb, const uint64_t* masks, 
  * into `total` (same record layout, once). */
 int dvgo_shade_wgrad(const float* G1, const float* gz, const uint64_t* masks, const float* W3,
                      const float* H1, const float* H2, const float* feat, int C, const float* emb, int E, const int64_t* ray_id, int64_t M,
-                     int width, int diffuse, int n_parts, float* part, float* total, void* stream);
+                     const int64_t* m_dev, int width, int diffuse, int n_parts, float* part, float* total, void* stream);
 
 /* ---------------------------------------------------------------------------------
  * "next" rows N1/N2: optimizer and regulariser kernels.
@@ -426,13 +433,14 @@ int dvgo_total_variation_add_grad_slab(const float* param, float* grad, float wx
  *   the pointer tables and numel are HOST arrays.
  * --------------------------------------------------------------------------------- */
 int dvgo_loss_fwd_bwd(const float* rgb_marched, const float* alphainv_last, const float* target, int64_t N,
-                      const float* raw_rgb, const float* weights, const int64_t* ray_id, int64_t M,
+                      const float* raw_rgb, const float* weights, const int64_t* ray_id, int64_t M, const int64_t* m_dev,
                       int64_t n_rays_global, float w_main, float w_ent, float w_per,
                       float* g_marched, float* g_last, float* g_raw_rgb, float* loss_out, void* stream);
 int dvgo_viewdir_embed(const float* viewdirs, const float* freq, int n_freq, int64_t N, float* emb, void* stream);
 int dvgo_adam_upd_multi(float* const* params, const float* const* grads, float* const* exp_avg,
                         float* const* exp_avg_sq, const int64_t* numel, int n_tensors, float step_size,
-                        float beta1, float beta2, float eps, void* stream);
+                        float beta1, float beta2, float eps,
+                        const float* step_size_dev /* NULL, or the step size on the device */, void* stream);
 
 #ifdef __cplusplus
 }

@@ -380,3 +380,46 @@ def test_resume_from_a_reference_written_checkpoint(fused):
     np.testing.assert_allclose(m.k0.detach().cpu().numpy(), g['k0'], atol=2e-3)
     for k, p in m.rgbnet.named_parameters():
         np.testing.assert_allclose(p.detach().cpu().numpy(), g['rgbnet_' + k], atol=5e-5)
+
+
+def test_captured_step_replays_to_the_same_parameters_as_eager_steps():
+    """TrainStep.capture(): the whole step as one HIP graph (sample count on the device, Adam step sizes in device
+    memory).  Five replayed steps on changing batches land on the parameters of five eager steps."""
+    from directvoxgo_amd.dvgo import DirectVoxGO
+    from directvoxgo_amd.scenes import lego_like_rays, synthetic_scene
+    from directvoxgo_amd.train import FINE_TRAIN, TrainStep
+    sc = synthetic_scene(world=48, n_rays=2048, seed=21, device='cuda')
+    batches = []
+    for b in range(8):
+        gen = torch.Generator().manual_seed(100 + b)
+        ro, rd, vd = lego_like_rays(2048, gen)
+        batches.append(tuple(t.cuda() for t in (ro, rd, vd, torch.rand(2048, 3, generator=gen))))
+    outs = []
+    for graph in (True, False):
+        torch.manual_seed(4)
+        m = DirectVoxGO(sc['xyz_min'], sc['xyz_max'], num_voxels=48 ** 3, num_voxels_base=48 ** 3, alpha_init=1e-2,
+                        fast_color_thres=1e-4, rgbnet_dim=12, rgbnet_width=128, rgbnet_direct=True).cuda()
+        with torch.no_grad():
+            m.density.copy_(sc['density']); m.k0.copy_(sc['k0']); m.mask_cache.mask.copy_(sc['mask'])
+        step = TrainStep(m, dict(FINE_TRAIN), dict(near=sc['near'], far=sc['far'], bg=1, stepsize=0.5))
+        losses = []
+        for s in range(3):                                          # warm-up steps: eager in both runs
+            losses.append(float(step(*batches[s], global_step=1 + s)))
+        if graph:
+            assert step.can_capture()
+            before = [p.detach().clone() for p in m.parameters()]
+            steps_before = {id(p): st['step'] for p, st in step.optimizer.state.items()}
+            assert step.capture(*batches[3], global_step=4, warmup=0)
+            for p, q in zip(m.parameters(), before):               # capturing runs no kernel and counts no step
+                assert torch.equal(p.detach(), q)
+            assert steps_before == {id(p): st['step'] for p, st in step.optimizer.state.items()}
+        for s in range(3, 8):
+            losses.append(float(step(*batches[s], global_step=1 + s)))
+        torch.cuda.synchronize()
+        assert step.optimizer.state[m.k0]['step'] == 8
+        outs.append((losses, [p.detach().clone() for p in m.parameters()], step.optimizer.param_groups[0]['lr']))
+    (la, pa, lra), (lb, pb, lrb) = outs
+    assert abs(lra - lrb) < 1e-12
+    np.testing.assert_allclose(la, lb, rtol=2e-4)
+    for x, y in zip(pa, pb):
+        _assert_same_up_to_adam_noise(x, y)

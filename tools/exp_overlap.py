@@ -43,7 +43,7 @@ L.call('dvgo_sample_pts_prepare', ptr(sc['rays_o']), ptr(sc['rays_d']), ptr(cfg.
 
 
 def bwd(stream):
-    L.call('dvgo_shade_bwd', ptr(g_rgb), ptr(rgb), ptr(masks), _i64(M), ptr(W1), ptr(W2), ptr(W3), _int(128), _int(39), _int(12),
+    L.call('dvgo_shade_bwd', ptr(g_rgb), ptr(rgb), ptr(masks), _i64(M), ptr(None), ptr(W1), ptr(W2), ptr(W3), _int(128), _int(39), _int(12),
            _int(0), ptr(g_feat), ptr(G1), ptr(gz), ctypes.c_void_p(stream.cuda_stream))
 
 
