@@ -19,51 +19,128 @@
 //           parameters: the gradient then never exists in HBM.
 #include "common.h"
 
-// exclusive scan of n int32 counts by ONE workgroup of 1024 threads: out[i] = sum of cnt[0..i), out[n] = total;
-// `copy` (optional) receives the same offsets (the fill cursors)
-template <typename OutT>
-__device__ __forceinline__ void block_scan_i32(const int32_t* __restrict__ cnt, int n, OutT* __restrict__ out,
-                                               int32_t* __restrict__ copy) {
-  __shared__ int s_wave[16];
-  __shared__ int s_carry;
+// Exclusive scan of n values by ONE workgroup of 1024 threads, 8192 values per pass (one pass for a training batch's rays
+// and for the bricks of a 160^3 grid): every thread loads its 8 values of the pass up front (coalesced: value r * 1024 +
+// tid), the 8 rows are scanned per wave with shuffles, the 8 x 16 wave totals by wave 0 through LDS, and each value is
+// handed its exclusive prefix (and itself).  One memory round trip and two barriers per pass.  Values are 64-bit so that
+// several running sums can ride in one scan.  Returns the total.
+template <typename Load, typename Store>
+__device__ __forceinline__ unsigned long long block_scan_u64(int n, Load load, Store store) {
+  constexpr int R = 8;
+  __shared__ unsigned long long s_part[R * 16];
+  __shared__ unsigned long long s_total;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) s_carry = 0;
-  __syncthreads();
-  for (int base = 0; base < n; base += 1024) {
-    const int i = base + tid;
-    const int c = (i < n) ? cnt[i] : 0;
-    int inc = c;
+  unsigned long long carry = 0ull;
+  for (int base = 0; base < n; base += R * 1024) {
+    unsigned long long v[R], inc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int i = base + r * 1024 + tid;
+      v[r] = (i < n) ? load(i) : 0ull;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) inc[r] = v[r];
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
-      const int o = __shfl_up(inc, d);
-      if (lane >= d) inc += o;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const unsigned long long o = __shfl_up(inc[r], d);
+        if (lane >= d) inc[r] += o;
+      }
     }
-    if (lane == 63) s_wave[wave] = inc;
+    if (lane == 63) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) s_part[r * 16 + wave] = inc[r];
+    }
     __syncthreads();
-    int wbase = s_carry;
-    for (int w = 0; w < wave; ++w) wbase += s_wave[w];
-    const int ex = wbase + inc - c;
-    if (i < n) { out[i] = (OutT)ex; if (copy) copy[i] = ex; }
+    if (wave == 0) {                               // the 128 wave totals, in value order: two per lane
+      const unsigned long long p0 = s_part[2 * lane], p1 = s_part[2 * lane + 1];
+      unsigned long long t = p0 + p1;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long o = __shfl_up(t, d);
+        if (lane >= d) t += o;
+      }
+      s_part[2 * lane] = t - p0 - p1;
+      s_part[2 * lane + 1] = t - p1;
+      if (lane == 63) s_total = t;
+    }
     __syncthreads();
-    if (tid == 1023) s_carry = ex + c;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int i = base + r * 1024 + tid;
+      if (i < n) store(i, carry + s_part[r * 16 + wave] + inc[r] - v[r], v[r]);
+    }
+    carry += s_total;
     __syncthreads();
   }
-  if (tid == 0) out[n] = (OutT)s_carry;
+  return carry;
+}
+
+// exclusive scan of n int32 counts: out[i] = sum of cnt[0..i), out[n] = total
+template <typename OutT>
+__device__ __forceinline__ void block_scan_i32(const int32_t* __restrict__ cnt, int n, OutT* __restrict__ out) {
+  const unsigned long long total = block_scan_u64(
+      n, [&](int i) { return (unsigned long long)cnt[i]; }, [&](int i, unsigned long long ex, unsigned long long) { out[i] = (OutT)ex; });
+  if (threadIdx.x == 0) out[n] = (OutT)total;
+}
+
+// Heavy bricks (a thin surface crossed by every ray: tens of thousands of entries where the median brick has hundreds)
+// are cut into SLICES of `slice_len` entries.  Slice 0 is the brick's own work item; the further slices are EXTRA work
+// items appended after the bricks, and the slices of a brick meet in scratch tiles (see brick_accumulate_kernel).
+// This scan turns the per-brick counts into
+//   off      [nb + 1]  first entry of each brick's list (and `cursor`, the fill cursors)
+//   extra    [nb + 1]  first extra work item of each brick (ceil(cnt / slice_len) - 1 of them, none for most)
+//   slot     [nb + 1]  first scratch tile of each brick: one per slice when it has more than one, else none
+//   extra_brick [<= n_extra_max]  the brick of every extra work item
+// and clears the counters, which then serve as the arrival counters of the slices.
+#define DVGO_BRICK_SLICE_DEFAULT 4096   // entries per work item
+
+__device__ __forceinline__ void brick_tables(int32_t* __restrict__ cnt, int nb, int32_t* __restrict__ off,
+                                             int32_t* __restrict__ cursor, int32_t* __restrict__ extra, int32_t* __restrict__ slot,
+                                             int32_t* __restrict__ extra_brick, int n_extra_max, int slice_len) {
+  // the three running sums in one 64-bit scan: entries (28 bits) | extra items (18) | scratch tiles (18)
+  auto slices = [&](int c) { return c > slice_len ? (c + slice_len - 1) / slice_len : 1; };
+  const unsigned long long total = block_scan_u64(
+      nb,
+      [&](int i) {
+        const int c = cnt[i];
+        if (!extra) return (unsigned long long)c;
+        const int ns = slices(c);
+        return (unsigned long long)c | ((unsigned long long)(ns - 1) << 28) | ((unsigned long long)(ns > 1 ? ns : 0) << 46);
+      },
+      [&](int i, unsigned long long ex, unsigned long long v) {
+        const int e0 = extra ? (int)(ex & 0xfffffffull) : (int)ex;
+        off[i] = e0; cursor[i] = e0;
+        if (extra) {
+          const int e1 = (int)((ex >> 28) & 0x3ffffull), ns = (int)((v >> 28) & 0x3ffffull) + 1;
+          extra[i] = e1; slot[i] = (int)(ex >> 46); cnt[i] = 0;
+          for (int k = 0; k + 1 < ns; ++k)
+            if (e1 + k < n_extra_max) extra_brick[e1 + k] = i;
+        }
+      });
+  if (threadIdx.x == 0) {
+    off[nb] = extra ? (int)(total & 0xfffffffull) : (int)total;
+    if (extra) { extra[nb] = (int)((total >> 28) & 0x3ffffull); slot[nb] = (int)(total >> 46); }
+  }
 }
 
 __global__ void __launch_bounds__(1024)
-brick_scan_kernel(const int32_t* __restrict__ cnt, int nb, int32_t* __restrict__ off, int32_t* __restrict__ cursor) {
-  block_scan_i32<int32_t>(cnt, nb, off, cursor);
+brick_scan_kernel(int32_t* __restrict__ cnt, int nb, int32_t* __restrict__ off, int32_t* __restrict__ cursor,
+                  int32_t* __restrict__ extra, int32_t* __restrict__ slot, int32_t* __restrict__ extra_brick, int n_extra_max,
+                  int slice_len) {
+  brick_tables(cnt, nb, off, cursor, extra, slot, extra_brick, n_extra_max, slice_len);
 }
 
 // the two scans between march_density and march_gather in one launch: workgroup 0 the kept-sample counts of the rays
-// (-> off3, int64 as the gather's output index), workgroup 1 the brick counts (-> offsets + fill cursors)
+// (-> off3, int64 as the gather's output index), workgroup 1 the brick tables
 __global__ void __launch_bounds__(1024)
 march_scans_kernel(const int32_t* __restrict__ n3, int n_rays, int64_t* __restrict__ off3,
-                   const int32_t* __restrict__ brick_cnt, int nb, int32_t* __restrict__ brick_off,
-                   int32_t* __restrict__ brick_cursor) {
-  if (blockIdx.x == 0) block_scan_i32<int64_t>(n3, n_rays, off3, nullptr);
-  else block_scan_i32<int32_t>(brick_cnt, nb, brick_off, brick_cursor);
+                   int32_t* __restrict__ brick_cnt, int nb, int32_t* __restrict__ brick_off,
+                   int32_t* __restrict__ brick_cursor, int32_t* __restrict__ extra, int32_t* __restrict__ slot,
+                   int32_t* __restrict__ extra_brick, int n_extra_max, int slice_len) {
+  if (blockIdx.x == 0) block_scan_i32<int64_t>(n3, n_rays, off3);
+  else brick_tables(brick_cnt, nb, brick_off, brick_cursor, extra, slot, extra_brick, n_extra_max, slice_len);
 }
 
 struct BrickAdam {
@@ -74,7 +151,7 @@ struct BrickAdam {
 };
 
 struct BrickGeom {
-  int X, Y, Z, BX, BY, BZ, nb;
+  int X, Y, Z, BX, BY, BZ, nb, slice_len;
   float mnx, mny, mnz, mxx, mxy, mxz, stepdist;      // sample positions are rebuilt from (ray, step) as in the forward
 };
 
@@ -89,8 +166,10 @@ __device__ __forceinline__ void adam4(float4& p, const float4 g, float4& m, floa
 // ADAM: 0 = write the dense gradients, 1 = apply the (masked) Adam update in place
 template <int C, int ADAM>
 __global__ void __launch_bounds__(256, 4)          // 4 workgroups per CU (LDS allows exactly 4): at most 128 VGPRs
-brick_accumulate_kernel(const int32_t* __restrict__ off, const int4* __restrict__ recs,
-                        const float* __restrict__ rays_start, const float* __restrict__ rays_dir,
+brick_accumulate_kernel(const int32_t* __restrict__ off, const int32_t* __restrict__ extra_off,
+                        const int32_t* __restrict__ slot_off, const int32_t* __restrict__ extra_brick,
+                        int32_t* __restrict__ arrive, float* __restrict__ scratch,
+                        const int4* __restrict__ recs, const float* __restrict__ rays_start, const float* __restrict__ rays_dir,
                         const float* __restrict__ g_feat, BrickGeom G, float* __restrict__ grad_k0,
                         float* __restrict__ grad_density, BrickAdam A) {
   constexpr int CE = C + 1;                      // the density gradient rides as channel C
@@ -111,15 +190,27 @@ brick_accumulate_kernel(const int32_t* __restrict__ off, const int4* __restrict_
   static_assert(sizeof(Lds) <= 40960, "4 workgroups per CU");
 
   if (A.ss_dev != nullptr) { A.ss_k = A.ss_dev[0]; A.ss_d = A.ss_dev[1]; }
-  // blocks b and b + 8 share an XCD (round-robin dispatch): give each XCD a contiguous range of bricks, so that the
-  // up-to-8 bricks listing one sample read its gradient row through the same L2
-  const int per = (G.nb + 7) >> 3;
-  const int b = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-  if (b >= G.nb) return;
+  // Work item -> (brick, slice).  The first nb8 = ceil8(nb) blocks are the bricks (slice 0): blocks i and i + 8 share an
+  // XCD (round-robin dispatch), so each XCD gets a contiguous range of bricks and the up-to-8 bricks listing one sample
+  // read its gradient row through the same L2.  The blocks behind them are the extra slices of heavy bricks.
+  const int nb8 = (G.nb + 7) & ~7;
+  int b, slice = 0;
+  if ((int)blockIdx.x < nb8) {
+    b = (int)(blockIdx.x & 7) * (nb8 >> 3) + (int)(blockIdx.x >> 3);
+    if (b >= G.nb) return;
+  } else {
+    const int x = (int)blockIdx.x - nb8;
+    if (x >= extra_off[G.nb]) return;
+    b = extra_brick[x];
+    slice = x - extra_off[b] + 1;
+  }
   const int bz = b % G.BZ, by = (b / G.BZ) % G.BY, bx = b / (G.BZ * G.BY);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int lo = off[b], n = off[b + 1] - lo;
-  if (ADAM && n == 0) return;                    // untouched brick: nothing to update
+  const int n_b = off[b + 1] - off[b];
+  if (ADAM && n_b == 0) return;                  // untouched brick: nothing to update
+  const int n_slices = (extra_off != nullptr && n_b > G.slice_len) ? (n_b + G.slice_len - 1) / G.slice_len : 1;
+  const int lo = off[b] + slice * G.slice_len;
+  const int n = n_slices > 1 ? min(G.slice_len, n_b - slice * G.slice_len) : n_b;
 
   float acc0[CE], acc1[CE];
 #pragma unroll
@@ -258,6 +349,44 @@ brick_accumulate_kernel(const int32_t* __restrict__ off, const int4* __restrict_
   }
   __syncthreads();
 
+  // ---- slices of a heavy brick meet here: every slice publishes its partial tile, the last one to arrive adds the others
+  // to its own and carries on to the epilogue (agent-scope release / acquire around the arrival ticket:
+  // cdna_hip_programming.md Guideline 16)
+  if (n_slices > 1) {
+    __shared__ int s_last;
+    const int slot0 = slot_off[b];
+    float4* mine = reinterpret_cast<float4*>(scratch + (int64_t)(slot0 + slice) * (512 * TS));
+    const float4* tile4 = reinterpret_cast<const float4*>(&u.tile[0][0]);
+    for (int q = tid; q < 512 * TS / 4; q += 256) mine[q] = tile4[q];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const int ticket = atomicAdd(&arrive[b], 1);
+      const int last = ticket == n_slices - 1;
+      if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    for (int k = 0; k < n_slices; ++k) {
+      if (k == slice) continue;
+      const float4* other = reinterpret_cast<const float4*>(scratch + (int64_t)(slot0 + k) * (512 * TS));
+      float4* t4 = reinterpret_cast<float4*>(&u.tile[0][0]);
+      for (int q = tid; q < 512 * TS / 4; q += 256) {
+        const float4 o = other[q];
+        float4 a = t4[q];
+        a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+        t4[q] = a;
+      }
+    }
+    __syncthreads();
+  }
+
   const int x0 = bx << DVGO_BRICK_LOG, y0 = by << DVGO_BRICK_LOG, z0 = bz << DVGO_BRICK_LOG;
   if constexpr (C == 12) {
     // 4 lanes per voxel: three float4 of features + the density scalar; 8 voxels in z = 384 contiguous bytes of k0.
@@ -347,27 +476,37 @@ int dvgo_n_bricks(int X, int Y, int Z) {
   return nb < ((int64_t)1 << 30) ? (int)nb : DVGO_ERANGE;
 }
 
-int dvgo_brick_scan(const int32_t* brick_cnt, int n_bricks, int32_t* brick_off, int32_t* brick_cursor, void* stream) {
+int dvgo_brick_scan(int32_t* brick_cnt, int n_bricks, int32_t* brick_off, int32_t* brick_cursor, int32_t* extra_off,
+                    int32_t* slot_off, int32_t* extra_brick, int n_extra_max, int slice_len, void* stream) {
   if (n_bricks < 0) return DVGO_EINVAL;
   if (!brick_cnt || !brick_off || !brick_cursor) return DVGO_EINVAL;
-  brick_scan_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(brick_cnt, n_bricks, brick_off, brick_cursor);
+  if (extra_off && (!slot_off || !extra_brick || n_extra_max < 0 || slice_len < 256)) return DVGO_EINVAL;
+  brick_scan_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(brick_cnt, n_bricks, brick_off, brick_cursor, extra_off, slot_off,
+                                                          extra_brick, n_extra_max, slice_len);
   DVGO_LAUNCH_CHECK();
   return 0;
 }
 
-int dvgo_march_scans(const int32_t* n3, int64_t n_rays, int64_t* off3, const int32_t* brick_cnt, int n_bricks,
-                     int32_t* brick_off, int32_t* brick_cursor, void* stream) {
+int dvgo_march_scans(const int32_t* n3, int64_t n_rays, int64_t* off3, int32_t* brick_cnt, int n_bricks,
+                     int32_t* brick_off, int32_t* brick_cursor, int32_t* extra_off, int32_t* slot_off, int32_t* extra_brick,
+                     int n_extra_max, int slice_len, void* stream) {
   if (n_rays < 0 || n_bricks < 0 || n_rays >= ((int64_t)1 << 31)) return DVGO_EINVAL;
   if (!off3 || (n_rays > 0 && !n3)) return DVGO_EINVAL;
   const bool bricks = brick_cnt != nullptr;
   if (bricks && (!brick_off || !brick_cursor)) return DVGO_EINVAL;
+  if (bricks && extra_off && (!slot_off || !extra_brick || n_extra_max < 0 || slice_len < 256)) return DVGO_EINVAL;
   march_scans_kernel<<<bricks ? 2 : 1, 1024, 0, (hipStream_t)stream>>>(n3, (int)n_rays, off3, brick_cnt, n_bricks, brick_off,
-                                                                        brick_cursor);
+                                                                        brick_cursor, extra_off, slot_off, extra_brick, n_extra_max,
+                                                                        slice_len);
   DVGO_LAUNCH_CHECK();
   return 0;
 }
 
-int dvgo_brick_accumulate(const int32_t* brick_off, const void* recs, const float* rays_start, const float* rays_dir,
+int dvgo_brick_slice(void) { return DVGO_BRICK_SLICE_DEFAULT; }
+
+int dvgo_brick_accumulate(const int32_t* brick_off, const int32_t* extra_off, const int32_t* slot_off,
+                          const int32_t* extra_brick, int32_t* arrive, float* scratch, int64_t n_extra_max, int slice_len,
+                          const void* recs, const float* rays_start, const float* rays_dir,
                           float stepdist, const float* xyz_min, const float* xyz_max, const float* grad_feat,
                           int C, int X, int Y, int Z, float* grad_k0, float* grad_density,
                           float* p_k0, float* m_k0, float* v_k0, float step_size_k0, int masked_k0,
@@ -377,6 +516,7 @@ int dvgo_brick_accumulate(const int32_t* brick_off, const void* recs, const floa
   if (nb < 0) return nb;
   const bool adam = p_k0 != nullptr;
   if (!brick_off || !recs || !rays_start || !rays_dir || !xyz_min || !xyz_max) return DVGO_EINVAL;
+  if (extra_off && (!slot_off || !extra_brick || !arrive || !scratch || n_extra_max < 0 || slice_len < 256)) return DVGO_EINVAL;
   if (adam && (!m_k0 || !v_k0 || !p_density || !m_density || !v_density)) return DVGO_EINVAL;
   if (!adam && (!grad_k0 || !grad_density)) return DVGO_EINVAL;
   if (C == 12 && ((((uintptr_t)grad_feat | (uintptr_t)grad_k0 | (uintptr_t)p_k0 | (uintptr_t)m_k0 | (uintptr_t)v_k0) & 15) != 0))
@@ -384,7 +524,7 @@ int dvgo_brick_accumulate(const int32_t* brick_off, const void* recs, const floa
   BrickGeom G;
   G.X = X; G.Y = Y; G.Z = Z;
   G.BX = (X + DVGO_BRICK - 1) >> DVGO_BRICK_LOG; G.BY = (Y + DVGO_BRICK - 1) >> DVGO_BRICK_LOG; G.BZ = (Z + DVGO_BRICK - 1) >> DVGO_BRICK_LOG;
-  G.nb = nb;
+  G.nb = nb; G.slice_len = slice_len;
   G.mnx = xyz_min[0]; G.mny = xyz_min[1]; G.mnz = xyz_min[2];
   G.mxx = xyz_max[0]; G.mxy = xyz_max[1]; G.mxz = xyz_max[2];
   G.stepdist = stepdist;
@@ -393,14 +533,18 @@ int dvgo_brick_accumulate(const int32_t* brick_off, const void* recs, const floa
   A.ss_k = step_size_k0; A.ss_d = step_size_density; A.beta1 = beta1; A.beta2 = beta2; A.eps = eps;
   A.ss_dev = step_sizes_dev;
   A.masked_k = masked_k0; A.masked_d = masked_density;
-  const int blocks = ((nb + 7) >> 3) << 3;
+  const int64_t items = ((nb + 7) & ~7) + (extra_off ? n_extra_max : 0);     // bricks (padded to the 8 XCDs), then extra slices
+  if (items >= ((int64_t)1 << 30)) return DVGO_ERANGE;
+  const int blocks = (int)items;
   hipStream_t s = (hipStream_t)stream;
 #define DVGO_BRICK_ACC(CC)                                                                                        \
   do {                                                                                                            \
-    if (adam) brick_accumulate_kernel<CC, 1><<<blocks, 256, 0, s>>>(brick_off, (const int4*)recs, rays_start, rays_dir, \
-                                                                     grad_feat, G, grad_k0, grad_density, A);       \
-    else brick_accumulate_kernel<CC, 0><<<blocks, 256, 0, s>>>(brick_off, (const int4*)recs, rays_start, rays_dir,  \
-                                                                grad_feat, G, grad_k0, grad_density, A);            \
+    if (adam) brick_accumulate_kernel<CC, 1><<<blocks, 256, 0, s>>>(brick_off, extra_off, slot_off, extra_brick, arrive, scratch, \
+                                                                     (const int4*)recs, rays_start, rays_dir,             \
+                                                                     grad_feat, G, grad_k0, grad_density, A);             \
+    else brick_accumulate_kernel<CC, 0><<<blocks, 256, 0, s>>>(brick_off, extra_off, slot_off, extra_brick, arrive, scratch,   \
+                                                                (const int4*)recs, rays_start, rays_dir,                  \
+                                                                grad_feat, G, grad_k0, grad_density, A);                  \
   } while (0)
   if (C == 12) DVGO_BRICK_ACC(12);
   else if (C == 9) DVGO_BRICK_ACC(9);

@@ -64,6 +64,7 @@ def _rec_stride(cfg, n_rays):
 # Owner-computes gradient scatter (csrc/brick.hip): samples are listed per 8x8x8 brick, one workgroup sums a brick;
 # no float atomics, no zero-fill.  The default whenever both grids want a gradient, share the lattice and the
 # feature grid is channels-last with a built channel count; the atomic scatters below remain as A/B variants.
+BRICK_SLICE = None          # entries per work item of the brick kernel (None: the library's default)
 BRICK_SCATTER = True
 BRICK_CHANNELS = (3, 4, 9, 12)
 
@@ -152,13 +153,20 @@ class _FusedMarch(torch.autograd.Function):
             # training: count, per 8^3 brick, the samples the backward will list for it (csrc/brick.hip)
             bricks = (BRICK_SCATTER and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and C in BRICK_CHANNELS
                       and tuple(density.shape[2:]) == (X, Y, Z) and (sC, sZ, sY, sX) == (1, C, Z * C, Y * Z * C)
-                      and k0.data_ptr() % 16 == 0 and N > 0)
-            brick_cnt = brick_off = brick_cur = None
+                      and k0.data_ptr() % 16 == 0 and N > 0 and 8 * cap < 1 << 31)       # int32 list offsets
+            brick_cnt = brick_off = brick_cur = extra_brick = None
+            n_extra_max = slice_len = 0
             if bricks:
                 nb = L.lib().dvgo_n_bricks(X, Y, Z)
                 brick_cnt = torch.zeros(nb, dtype=torch.int32, device=dev)
-                brick_off = torch.empty(nb + 1, dtype=torch.int32, device=dev)
+                brick_off = torch.empty((3, nb + 1), dtype=torch.int32, device=dev)    # list offsets, extra items, scratch tiles
                 brick_cur = torch.empty(nb, dtype=torch.int32, device=dev)
+                # heavy bricks: extra work items <= entries / slice, entries <= 8 per record slot (the slice tables are
+                # built for up to 2^28 entries; render-sized batches beyond that run one workgroup per brick)
+                if 8 * cap < 1 << 28:
+                    slice_len = BRICK_SLICE or L.lib().dvgo_brick_slice()
+                    n_extra_max = 8 * max(cap, 1) // slice_len
+                    extra_brick = torch.empty(max(n_extra_max, 1), dtype=torch.int32, device=dev)
             mask = cfg.mask
             mshape = mask.shape if mask is not None else (0, 0, 0)
             L.call('dvgo_march_density', ptr(start), ptr(dirs), ptr(n_steps), ptr(cum), _i64(stride), _i64(N),
@@ -169,11 +177,17 @@ class _FusedMarch(torch.autograd.Function):
             n_entries = 0
             if N <= 16384:              # both scans in one launch (one workgroup each)
                 L.call('dvgo_march_scans', ptr(n3), _i64(N), ptr(off3), ptr(brick_cnt), _int(nb if bricks else 0),
-                       ptr(brick_off), ptr(brick_cur), st)
+                       ptr(brick_off[0] if bricks else None), ptr(brick_cur),
+                       ptr(brick_off[1] if extra_brick is not None else None),
+                       ptr(brick_off[2] if extra_brick is not None else None), ptr(extra_brick), _int(n_extra_max),
+                       _int(slice_len), st)
             else:                       # render-sized batches: the multi-workgroup scan
                 L.call('dvgo_exclusive_scan_i32', ptr(n3), _i64(N), ptr(off3), st)
                 if bricks:
-                    L.call('dvgo_brick_scan', ptr(brick_cnt), _int(nb), ptr(brick_off), ptr(brick_cur), st)
+                    L.call('dvgo_brick_scan', ptr(brick_cnt), _int(nb), ptr(brick_off[0]), ptr(brick_cur),
+                           ptr(brick_off[1] if extra_brick is not None else None),
+                           ptr(brick_off[2] if extra_brick is not None else None), ptr(extra_brick), _int(n_extra_max),
+                           _int(slice_len), st)
             if capacity and stride > 0 and bricks:
                 # training step (train.py): the surviving-sample count stays on the device.  The outputs are sized by
                 # their upper bound -- every step of every ray -- and every consumer is handed off3[N] as a device
@@ -181,7 +195,7 @@ class _FusedMarch(torch.autograd.Function):
                 M3 = stride * N
                 n_entries = 8 * M3                              # a sample touches at most 2 x 2 x 2 bricks
             elif bricks:
-                M3, n_entries = torch.stack((off3[-1], brick_off[-1].long())).tolist()   # the one host sync
+                M3, n_entries = torch.stack((off3[-1], brick_off[0, -1].long())).tolist()   # the one host sync
             else:
                 M3 = int(off3[-1].item())                      # the one host sync of the fused forward
             ray_id = torch.empty(M3, dtype=torch.int64, device=dev)
@@ -195,7 +209,7 @@ class _FusedMarch(torch.autograd.Function):
                    ptr(weights), ptr(alpha), ptr(feat), st)
         ctx.cfg = cfg
         ctx.geom = (X, Y, Z, C, sC, sX, sY, sZ, stride, N)
-        ctx.bricks = (brick_off, brick_cur, n_entries) if bricks else None
+        ctx.bricks = (brick_off, brick_cur, brick_cnt, extra_brick, slice_len, n_entries) if bricks else None
         ctx.padded = bool(capacity and stride > 0 and bricks)
         ctx.density_meta, ctx.k0_meta = density, k0
         ctx.save_for_backward(rec2, n2, n_steps, cum if cum is not None else n_steps, off3, start, dirs, last,
@@ -233,17 +247,25 @@ class _FusedMarch(torch.autograd.Function):
                 raise RuntimeError('capacity-mode forward (device-side sample count) needs the brick scatter backward for both grids')
             if ctx.bricks is not None and want_k0 and want_d and BRICK_SCATTER:
                 # owner-computes scatter: list every sample per brick, then one workgroup sums each brick
-                brick_off, brick_cur, E = ctx.bricks
+                brick_off, brick_cur, arrive, extra_brick, slice_len, E = ctx.bricks
                 ctx.bricks = None                               # the fill cursors are consumed: one backward per forward
                 recs = torch.empty((max(E, 1), 4), dtype=torch.int32, device=dev)
                 density_bwd(None, 1, None, brick_cur, recs)
                 g_feat = g_feat.contiguous()
+                # heavy bricks run as several work items (slices of the list) that meet in scratch tiles
+                if extra_brick is not None:
+                    n_extra_max = min(extra_brick.shape[0], E // slice_len)
+                    tiles = torch.empty((2 * (E // slice_len) + 2, 512 * ((C + 4) // 4 * 4)), dtype=torch.float32, device=dev)
+                    items = (ptr(brick_off[0]), ptr(brick_off[1]), ptr(brick_off[2]), ptr(extra_brick), ptr(arrive),
+                             ptr(tiles), _i64(n_extra_max), _int(slice_len))
+                else:
+                    items = (ptr(brick_off[0]), ptr(None), ptr(None), ptr(None), ptr(None), ptr(None), _i64(0), _int(0))
                 cap = grid_rows_capture._active
                 fuse = (cap is not None and cap.adam is not None and not cap.stepped and cap.density is ctx.density_meta
                         and cap.k0 is ctx.k0_meta)
                 if fuse:
                     tail = cap.adam()
-                    L.call('dvgo_brick_accumulate', ptr(brick_off), ptr(recs), ptr(start), ptr(dirs), _flt(cfg.stepdist),
+                    L.call('dvgo_brick_accumulate', *items, ptr(recs), ptr(start), ptr(dirs), _flt(cfg.stepdist),
                            cfg.xyz_min_h, cfg.xyz_max_h, ptr(g_feat), _int(C), _int(X), _int(Y), _int(Z), ptr(None), ptr(None),
                            *tail, st)
                     cap.stepped = True
@@ -251,7 +273,7 @@ class _FusedMarch(torch.autograd.Function):
                 grad_k0 = torch.empty_like(ctx.k0_meta, memory_format=torch.preserve_format)
                 grad_density = torch.empty_like(ctx.density_meta)
                 assert grad_k0.stride() == ctx.k0_meta.stride() and grad_density.is_contiguous()
-                L.call('dvgo_brick_accumulate', ptr(brick_off), ptr(recs), ptr(start), ptr(dirs), _flt(cfg.stepdist),
+                L.call('dvgo_brick_accumulate', *items, ptr(recs), ptr(start), ptr(dirs), _flt(cfg.stepdist),
                        cfg.xyz_min_h, cfg.xyz_max_h, ptr(g_feat), _int(C), _int(X), _int(Y), _int(Z), ptr(grad_k0),
                        ptr(grad_density), ptr(None), ptr(None), ptr(None), _flt(0), _int(0),
                        ptr(None), ptr(None), ptr(None), _flt(0), _int(0), _flt(0), _flt(0), _flt(0), ptr(None), st)

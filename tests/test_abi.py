@@ -44,9 +44,9 @@ def test_argument_validation_returns_error_codes_before_any_launch(so_path):
     one = vp(16)      # any non-null value: rejected on shape before it could be dereferenced
     assert lib.dvgo_grid_grad_split(one, i64(10), ctypes.c_int(12), ctypes.c_int(12), one, one, null) == -2   # rows of 16 only
     # colour head: shapes outside the built set are DVGO_ERANGE (the caller then keeps the torch modules)
-    args = [one, ctypes.c_int(12), one, ctypes.c_int(27), one, i64(5), one, one, one, one, one, one]
-    assert lib.dvgo_shade_fwd(*args, ctypes.c_int(96), ctypes.c_int(39), ctypes.c_int(0), one, null, null, null, null) == -2
-    assert lib.dvgo_shade_fwd(*args, ctypes.c_int(128), ctypes.c_int(38), ctypes.c_int(0), one, null, null, null, null) == -1  # d_in != C + E
+    args = [one, ctypes.c_int(12), one, ctypes.c_int(27), one, i64(5), null, one, one, one, one, one, one]
+    assert lib.dvgo_shade_fwd(*args, ctypes.c_int(96), ctypes.c_int(39), ctypes.c_int(0), one, null, null, null, null, null) == -2
+    assert lib.dvgo_shade_fwd(*args, ctypes.c_int(128), ctypes.c_int(38), ctypes.c_int(0), one, null, null, null, null, null) == -1  # d_in != C + E
     assert lib.dvgo_set_tuning(ctypes.c_int(99), ctypes.c_int(1)) == -1
 
 

@@ -163,7 +163,49 @@ def test_brick_lists_cover_every_sample_corner_exactly_once():
     cfg = m._march_cfg(sc['near'], sc['far'], sc['stepsize'])
     w, alpha, last, feat, ray_id, step_id, off3 = F.fused_march(m.density, m.k0, sc['rays_o'], sc['rays_d'], cfg)
     node = feat.grad_fn
-    brick_off, _, E = node.bricks
-    off = brick_off.cpu().numpy()
+    brick_off, _, _, _, _, E = node.bricks
+    off = brick_off[0].cpu().numpy()
     assert off[0] == 0 and off[-1] == E and np.all(np.diff(off) >= 0)
     assert E >= w.numel()                         # every kept sample is listed at least once (plus alpha-only ones)
+
+
+def test_heavy_bricks_are_split_into_slices_that_meet_in_scratch_tiles(monkeypatch):
+    """A thin slab of matter crossed by 16384 rays: a few bricks collect far more than the slice length, so their
+    lists are summed by several workgroups that meet through the scratch tiles and the arrival counters.  Dense gradients
+    and the fused Adam update must match the atomic scatter / the dense path as everywhere else."""
+    from directvoxgo_amd import _lib as L, fused as F
+    from directvoxgo_amd.train import FINE_TRAIN, TrainStep
+    assert L.lib().dvgo_brick_slice() >= 256
+    slice_len = 1024
+    monkeypatch.setattr(F, 'BRICK_SLICE', slice_len)
+    sc, m = _model(48, 16384, width=128, direct=True)
+    with torch.no_grad():                                    # matter only in a 6-voxel slab: every ray's samples pile up there
+        d = torch.full_like(m.density, -20.0)
+        d[:, :, 20:26] = 6.0
+        m.density.copy_(d)
+        m.mask_cache.mask.fill_(True)
+    _, gd_n, gk_n = _grads(m, sc, 'naive')
+    _, gd, gk = _grads(m, sc, 'brick')
+    _close(gd, gd_n)
+    _close(gk, gk_n)
+    assert torch.equal(gk != 0, gk_n != 0)
+    # the lists really were sliced
+    cfg = m._march_cfg(sc['near'], sc['far'], sc['stepsize'])
+    w, alpha, last, feat, ray_id, step_id, off3 = F.fused_march(m.density, m.k0, sc['rays_o'], sc['rays_d'], cfg)
+    tables = feat.grad_fn.bricks[0].cpu().numpy()
+    counts = np.diff(tables[0])
+    assert counts.max() > 2 * slice_len
+    assert tables[1][-1] >= 2 and tables[2][-1] >= 3                       # extra work items and scratch tiles in use
+    assert np.array_equal(np.diff(tables[1]), np.maximum(1, -(-counts // slice_len)) - 1)
+    # and the fused Adam epilogue of a sliced brick == dense gradients + MaskedAdam.step
+    outs = []
+    for fused_adam in (True, False):
+        sc2, m2 = _model(48, 16384, width=128, direct=True)
+        with torch.no_grad():
+            m2.density.copy_(d); m2.mask_cache.mask.fill_(True)
+        step = TrainStep(m2, dict(FINE_TRAIN), dict(near=sc2['near'], far=sc2['far'], bg=1, stepsize=sc2['stepsize']),
+                         rows_adam=fused_adam)
+        step(sc2['rays_o'], sc2['rays_d'], sc2['viewdirs'], sc2['target'], global_step=5000)
+        outs.append((m2.density.detach().clone(), m2.k0.detach().clone(), step.optimizer.state[m2.k0]['exp_avg'].clone()))
+    _close(outs[0][2], outs[1][2], rtol=2e-4)
+    assert float((outs[0][1] - outs[1][1]).abs().max()) <= 2e-3 and float((outs[0][0] - outs[1][0]).abs().max()) <= 2e-3

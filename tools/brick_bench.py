@@ -19,6 +19,8 @@ ap.add_argument('--steps', type=int, default=20)
 ap.add_argument('--world', type=int, default=160)
 ap.add_argument('--rays', type=int, default=8192)
 ap.add_argument('--workload', default='roofline')
+ap.add_argument('--slice', type=int, default=0, help='entries per work item of the brick kernel (0: library default)')
+ap.add_argument('--hist', action='store_true', help='print the distribution of per-brick list lengths')
 args = ap.parse_args()
 
 NAMES = ['dvgo_sample_pts_prepare', 'dvgo_march_density', 'dvgo_march_scans', 'dvgo_exclusive_scan_i32', 'dvgo_march_gather', 'dvgo_march_composite', 'dvgo_march_composite_bwd', 'dvgo_shade_fwd', 'dvgo_shade_bwd', 'dvgo_shade_wgrad', 'dvgo_brick_scan', 'dvgo_march_density_bwd', 'dvgo_brick_accumulate', 'dvgo_march_feat_bwd',
@@ -34,6 +36,15 @@ def run(tag, brick, rows_adam):
     with torch.no_grad():
         m.density.copy_(sc['density']); m.k0.copy_(sc['k0']); m.mask_cache.mask.copy_(sc['mask'])
     F.BRICK_SCATTER = brick
+    F.BRICK_SLICE = args.slice or None
+    if args.hist and brick and rows_adam:
+        import numpy as np
+        cfg = m._march_cfg(sc['near'], sc['far'], 0.5)
+        out = F.fused_march(m.density, m.k0, sc['rays_o'], sc['rays_d'], cfg)
+        c = np.diff(out[3].grad_fn.bricks[0][0].cpu().numpy())
+        nz = c[c > 0]
+        print('bricks', len(c), 'non-empty', len(nz), 'entries', int(c.sum()), 'percentiles 50/90/99/max',
+              [int(np.percentile(nz, q)) for q in (50, 90, 99, 100)])
     step = TrainStep(m, dict(FINE_TRAIN), dict(near=sc['near'], far=sc['far'], bg=1, stepsize=0.5), rows_adam=rows_adam,
                      overlap_wgrad=False)
     b = (sc['rays_o'], sc['rays_d'], sc['viewdirs'], sc['target'])
@@ -51,5 +62,6 @@ def run(tag, brick, rows_adam):
 
 run('brick + fused Adam', True, True)
 run('brick -> dense grads + dense Adam', True, False)
-run('atomic rows + adam_rows', False, True)
-run('atomic rows -> split + dense Adam', False, False)
+if not args.slice:
+    run('atomic rows + adam_rows', False, True)
+    run('atomic rows -> split + dense Adam', False, False)
