@@ -91,45 +91,46 @@ __device__ __forceinline__ void block_scan_i32(const int32_t* __restrict__ cnt, 
 // This scan turns the per-brick counts into
 //   off      [nb + 1]  first entry of each brick's list (and `cursor`, the fill cursors)
 //   extra    [nb + 1]  first extra work item of each brick (ceil(cnt / slice_len) - 1 of them, none for most)
-//   slot     [nb + 1]  first scratch tile of each brick: one per slice when it has more than one, else none
+//   active   [nb + 1]  the non-empty bricks, in brick order; active[nb] = their number (a sparse scene touches a tenth
+//                      of the bricks: the workgroups beyond that number leave after one load)
 //   extra_brick [<= n_extra_max]  the brick of every extra work item
 // and clears the counters, which then serve as the arrival counters of the slices.
-#define DVGO_BRICK_SLICE_DEFAULT 4096   // entries per work item
+#define DVGO_BRICK_SLICE_DEFAULT 1024   // entries per work item
 
 __device__ __forceinline__ void brick_tables(int32_t* __restrict__ cnt, int nb, int32_t* __restrict__ off,
-                                             int32_t* __restrict__ cursor, int32_t* __restrict__ extra, int32_t* __restrict__ slot,
+                                             int32_t* __restrict__ cursor, int32_t* __restrict__ extra, int32_t* __restrict__ active,
                                              int32_t* __restrict__ extra_brick, int n_extra_max, int slice_len) {
-  // the three running sums in one 64-bit scan: entries (28 bits) | extra items (18) | scratch tiles (18)
+  // the three running sums in one 64-bit scan: entries (28 bits) | extra items (18) | non-empty bricks (18)
   auto slices = [&](int c) { return c > slice_len ? (c + slice_len - 1) / slice_len : 1; };
   const unsigned long long total = block_scan_u64(
       nb,
       [&](int i) {
         const int c = cnt[i];
         if (!extra) return (unsigned long long)c;
-        const int ns = slices(c);
-        return (unsigned long long)c | ((unsigned long long)(ns - 1) << 28) | ((unsigned long long)(ns > 1 ? ns : 0) << 46);
+        return (unsigned long long)c | ((unsigned long long)(slices(c) - 1) << 28) | ((unsigned long long)(c > 0) << 46);
       },
       [&](int i, unsigned long long ex, unsigned long long v) {
         const int e0 = extra ? (int)(ex & 0xfffffffull) : (int)ex;
         off[i] = e0; cursor[i] = e0;
         if (extra) {
-          const int e1 = (int)((ex >> 28) & 0x3ffffull), ns = (int)((v >> 28) & 0x3ffffull) + 1;
-          extra[i] = e1; slot[i] = (int)(ex >> 46); cnt[i] = 0;
-          for (int k = 0; k + 1 < ns; ++k)
+          const int e1 = (int)((ex >> 28) & 0x3ffffull), n_extra = (int)((v >> 28) & 0x3ffffull);
+          extra[i] = e1; cnt[i] = 0;
+          if (v >> 46) active[(int)(ex >> 46)] = i;
+          for (int k = 0; k < n_extra; ++k)
             if (e1 + k < n_extra_max) extra_brick[e1 + k] = i;
         }
       });
   if (threadIdx.x == 0) {
     off[nb] = extra ? (int)(total & 0xfffffffull) : (int)total;
-    if (extra) { extra[nb] = (int)((total >> 28) & 0x3ffffull); slot[nb] = (int)(total >> 46); }
+    if (extra) { extra[nb] = (int)((total >> 28) & 0x3ffffull); active[nb] = (int)(total >> 46); }
   }
 }
 
 __global__ void __launch_bounds__(1024)
 brick_scan_kernel(int32_t* __restrict__ cnt, int nb, int32_t* __restrict__ off, int32_t* __restrict__ cursor,
-                  int32_t* __restrict__ extra, int32_t* __restrict__ slot, int32_t* __restrict__ extra_brick, int n_extra_max,
+                  int32_t* __restrict__ extra, int32_t* __restrict__ active, int32_t* __restrict__ extra_brick, int n_extra_max,
                   int slice_len) {
-  brick_tables(cnt, nb, off, cursor, extra, slot, extra_brick, n_extra_max, slice_len);
+  brick_tables(cnt, nb, off, cursor, extra, active, extra_brick, n_extra_max, slice_len);
 }
 
 // the two scans between march_density and march_gather in one launch: workgroup 0 the kept-sample counts of the rays
@@ -137,10 +138,10 @@ brick_scan_kernel(int32_t* __restrict__ cnt, int nb, int32_t* __restrict__ off, 
 __global__ void __launch_bounds__(1024)
 march_scans_kernel(const int32_t* __restrict__ n3, int n_rays, int64_t* __restrict__ off3,
                    int32_t* __restrict__ brick_cnt, int nb, int32_t* __restrict__ brick_off,
-                   int32_t* __restrict__ brick_cursor, int32_t* __restrict__ extra, int32_t* __restrict__ slot,
+                   int32_t* __restrict__ brick_cursor, int32_t* __restrict__ extra, int32_t* __restrict__ active,
                    int32_t* __restrict__ extra_brick, int n_extra_max, int slice_len) {
   if (blockIdx.x == 0) block_scan_i32<int64_t>(n3, n_rays, off3);
-  else brick_tables(brick_cnt, nb, brick_off, brick_cursor, extra, slot, extra_brick, n_extra_max, slice_len);
+  else brick_tables(brick_cnt, nb, brick_off, brick_cursor, extra, active, extra_brick, n_extra_max, slice_len);
 }
 
 struct BrickAdam {
@@ -151,7 +152,7 @@ struct BrickAdam {
 };
 
 struct BrickGeom {
-  int X, Y, Z, BX, BY, BZ, nb, slice_len;
+  int X, Y, Z, BX, BY, BZ, nb, slice_len, n_extra_max;
   float mnx, mny, mnz, mxx, mxy, mxz, stepdist;      // sample positions are rebuilt from (ray, step) as in the forward
 };
 
@@ -167,7 +168,7 @@ __device__ __forceinline__ void adam4(float4& p, const float4 g, float4& m, floa
 template <int C, int ADAM>
 __global__ void __launch_bounds__(256, 4)          // 4 workgroups per CU (LDS allows exactly 4): at most 128 VGPRs
 brick_accumulate_kernel(const int32_t* __restrict__ off, const int32_t* __restrict__ extra_off,
-                        const int32_t* __restrict__ slot_off, const int32_t* __restrict__ extra_brick,
+                        const int32_t* __restrict__ active, const int32_t* __restrict__ extra_brick,
                         int32_t* __restrict__ arrive, float* __restrict__ scratch,
                         const int4* __restrict__ recs, const float* __restrict__ rays_start, const float* __restrict__ rays_dir,
                         const float* __restrict__ g_feat, BrickGeom G, float* __restrict__ grad_k0,
@@ -192,12 +193,22 @@ brick_accumulate_kernel(const int32_t* __restrict__ off, const int32_t* __restri
   if (A.ss_dev != nullptr) { A.ss_k = A.ss_dev[0]; A.ss_d = A.ss_dev[1]; }
   // Work item -> (brick, slice).  The first nb8 = ceil8(nb) blocks are the bricks (slice 0): blocks i and i + 8 share an
   // XCD (round-robin dispatch), so each XCD gets a contiguous range of bricks and the up-to-8 bricks listing one sample
-  // read its gradient row through the same L2.  The blocks behind them are the extra slices of heavy bricks.
+  // read its gradient row through the same L2.  With the fused update only the non-empty bricks matter: the blocks then
+  // walk the `active` list instead (the dense-gradient form must also write the zeros of the others).  The blocks behind
+  // the bricks are the extra slices of heavy bricks.
   const int nb8 = (G.nb + 7) & ~7;
   int b, slice = 0;
   if ((int)blockIdx.x < nb8) {
-    b = (int)(blockIdx.x & 7) * (nb8 >> 3) + (int)(blockIdx.x >> 3);
-    if (b >= G.nb) return;
+    if (ADAM && active != nullptr) {
+      const int n_active = active[G.nb];
+      const int per = (n_active + 7) >> 3, r = (int)(blockIdx.x >> 3);
+      const int idx = (int)(blockIdx.x & 7) * per + r;
+      if (r >= per || idx >= n_active) return;
+      b = active[idx];
+    } else {
+      b = (int)(blockIdx.x & 7) * (nb8 >> 3) + (int)(blockIdx.x >> 3);
+      if (b >= G.nb) return;
+    }
   } else {
     const int x = (int)blockIdx.x - nb8;
     if (x >= extra_off[G.nb]) return;
@@ -350,38 +361,35 @@ brick_accumulate_kernel(const int32_t* __restrict__ off, const int32_t* __restri
   __syncthreads();
 
   // ---- slices of a heavy brick meet here: every slice publishes its partial tile, the last one to arrive adds the others
-  // to its own and carries on to the epilogue (agent-scope release / acquire around the arrival ticket:
-  // cdna_hip_programming.md Guideline 16)
+  // to its own and carries on to the epilogue.  The tiles travel as write-through (sc1) stores and are read back with sc1
+  // loads, so neither side needs an agent-scope fence (cdna_hip_programming.md Guideline 16, R1): a release fence would
+  // write back this XCD's whole L2, which is full of the dirty lines of the Adam epilogues -- measured at 1000 slices
+  // per launch it cost more than the entire kernel.  Tile of (brick, slice k >= 1) = extra item index; of slice 0 =
+  // n_extra_max + the brick's first extra item index.
   if (n_slices > 1) {
     __shared__ int s_last;
-    const int slot0 = slot_off[b];
-    float4* mine = reinterpret_cast<float4*>(scratch + (int64_t)(slot0 + slice) * (512 * TS));
-    const float4* tile4 = reinterpret_cast<const float4*>(&u.tile[0][0]);
-    for (int q = tid; q < 512 * TS / 4; q += 256) mine[q] = tile4[q];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    using u64 = unsigned long long;
+    constexpr int TILE8 = 512 * TS / 2;                              // 8-byte granules per tile
+    const int x_first = extra_off[b];
+    auto tile_of = [&](int k) { return scratch + (int64_t)(k == 0 ? G.n_extra_max + x_first : x_first + k - 1) * (512 * TS); };
+    u64* mine = reinterpret_cast<u64*>(tile_of(slice));
+    const u64* tile8 = reinterpret_cast<const u64*>(&u.tile[0][0]);
+    for (int q = tid; q < TILE8; q += 256) __hip_atomic_store(mine + q, tile8[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // every storing wave drains before the ticket
     __syncthreads();
-    if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const int ticket = atomicAdd(&arrive[b], 1);
-      const int last = ticket == n_slices - 1;
-      if (last) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      s_last = last;
-    }
+    if (tid == 0) s_last = __hip_atomic_fetch_add(&arrive[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_slices - 1;
     __syncthreads();
     if (!s_last) return;
     for (int k = 0; k < n_slices; ++k) {
       if (k == slice) continue;
-      const float4* other = reinterpret_cast<const float4*>(scratch + (int64_t)(slot0 + k) * (512 * TS));
-      float4* t4 = reinterpret_cast<float4*>(&u.tile[0][0]);
-      for (int q = tid; q < 512 * TS / 4; q += 256) {
-        const float4 o = other[q];
-        float4 a = t4[q];
-        a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
-        t4[q] = a;
+      const u64* other = reinterpret_cast<const u64*>(tile_of(k));
+      float2* t2 = reinterpret_cast<float2*>(&u.tile[0][0]);
+      for (int q = tid; q < TILE8; q += 256) {
+        const u64 raw = __hip_atomic_load(other + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        float2 a = t2[q];
+        a.x += __uint_as_float((unsigned)raw);
+        a.y += __uint_as_float((unsigned)(raw >> 32));
+        t2[q] = a;
       }
     }
     __syncthreads();
@@ -477,26 +485,27 @@ int dvgo_n_bricks(int X, int Y, int Z) {
 }
 
 int dvgo_brick_scan(int32_t* brick_cnt, int n_bricks, int32_t* brick_off, int32_t* brick_cursor, int32_t* extra_off,
-                    int32_t* slot_off, int32_t* extra_brick, int n_extra_max, int slice_len, void* stream) {
+                    int32_t* active, int32_t* extra_brick, int n_extra_max, int slice_len, void* stream) {
   if (n_bricks < 0) return DVGO_EINVAL;
   if (!brick_cnt || !brick_off || !brick_cursor) return DVGO_EINVAL;
-  if (extra_off && (!slot_off || !extra_brick || n_extra_max < 0 || slice_len < 256)) return DVGO_EINVAL;
-  brick_scan_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(brick_cnt, n_bricks, brick_off, brick_cursor, extra_off, slot_off,
+  if (extra_off && (!active || !extra_brick || n_extra_max < 0 || slice_len < 256 || n_bricks >= (1 << 18))) return DVGO_EINVAL;
+  brick_scan_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(brick_cnt, n_bricks, brick_off, brick_cursor, extra_off, active,
                                                           extra_brick, n_extra_max, slice_len);
   DVGO_LAUNCH_CHECK();
   return 0;
 }
 
 int dvgo_march_scans(const int32_t* n3, int64_t n_rays, int64_t* off3, int32_t* brick_cnt, int n_bricks,
-                     int32_t* brick_off, int32_t* brick_cursor, int32_t* extra_off, int32_t* slot_off, int32_t* extra_brick,
+                     int32_t* brick_off, int32_t* brick_cursor, int32_t* extra_off, int32_t* active, int32_t* extra_brick,
                      int n_extra_max, int slice_len, void* stream) {
   if (n_rays < 0 || n_bricks < 0 || n_rays >= ((int64_t)1 << 31)) return DVGO_EINVAL;
   if (!off3 || (n_rays > 0 && !n3)) return DVGO_EINVAL;
   const bool bricks = brick_cnt != nullptr;
   if (bricks && (!brick_off || !brick_cursor)) return DVGO_EINVAL;
-  if (bricks && extra_off && (!slot_off || !extra_brick || n_extra_max < 0 || slice_len < 256)) return DVGO_EINVAL;
+  if (bricks && extra_off && (!active || !extra_brick || n_extra_max < 0 || slice_len < 256 || n_bricks >= (1 << 18)))
+    return DVGO_EINVAL;
   march_scans_kernel<<<bricks ? 2 : 1, 1024, 0, (hipStream_t)stream>>>(n3, (int)n_rays, off3, brick_cnt, n_bricks, brick_off,
-                                                                        brick_cursor, extra_off, slot_off, extra_brick, n_extra_max,
+                                                                        brick_cursor, extra_off, active, extra_brick, n_extra_max,
                                                                         slice_len);
   DVGO_LAUNCH_CHECK();
   return 0;
@@ -504,7 +513,7 @@ int dvgo_march_scans(const int32_t* n3, int64_t n_rays, int64_t* off3, int32_t* 
 
 int dvgo_brick_slice(void) { return DVGO_BRICK_SLICE_DEFAULT; }
 
-int dvgo_brick_accumulate(const int32_t* brick_off, const int32_t* extra_off, const int32_t* slot_off,
+int dvgo_brick_accumulate(const int32_t* brick_off, const int32_t* extra_off, const int32_t* active,
                           const int32_t* extra_brick, int32_t* arrive, float* scratch, int64_t n_extra_max, int slice_len,
                           const void* recs, const float* rays_start, const float* rays_dir,
                           float stepdist, const float* xyz_min, const float* xyz_max, const float* grad_feat,
@@ -516,7 +525,7 @@ int dvgo_brick_accumulate(const int32_t* brick_off, const int32_t* extra_off, co
   if (nb < 0) return nb;
   const bool adam = p_k0 != nullptr;
   if (!brick_off || !recs || !rays_start || !rays_dir || !xyz_min || !xyz_max) return DVGO_EINVAL;
-  if (extra_off && (!slot_off || !extra_brick || !arrive || !scratch || n_extra_max < 0 || slice_len < 256)) return DVGO_EINVAL;
+  if (extra_off && (!active || !extra_brick || !arrive || !scratch || n_extra_max < 0 || slice_len < 256)) return DVGO_EINVAL;
   if (adam && (!m_k0 || !v_k0 || !p_density || !m_density || !v_density)) return DVGO_EINVAL;
   if (!adam && (!grad_k0 || !grad_density)) return DVGO_EINVAL;
   if (C == 12 && ((((uintptr_t)grad_feat | (uintptr_t)grad_k0 | (uintptr_t)p_k0 | (uintptr_t)m_k0 | (uintptr_t)v_k0) & 15) != 0))
@@ -524,7 +533,7 @@ int dvgo_brick_accumulate(const int32_t* brick_off, const int32_t* extra_off, co
   BrickGeom G;
   G.X = X; G.Y = Y; G.Z = Z;
   G.BX = (X + DVGO_BRICK - 1) >> DVGO_BRICK_LOG; G.BY = (Y + DVGO_BRICK - 1) >> DVGO_BRICK_LOG; G.BZ = (Z + DVGO_BRICK - 1) >> DVGO_BRICK_LOG;
-  G.nb = nb; G.slice_len = slice_len;
+  G.nb = nb; G.slice_len = slice_len; G.n_extra_max = (int)n_extra_max;
   G.mnx = xyz_min[0]; G.mny = xyz_min[1]; G.mnz = xyz_min[2];
   G.mxx = xyz_max[0]; G.mxy = xyz_max[1]; G.mxz = xyz_max[2];
   G.stepdist = stepdist;
@@ -539,10 +548,10 @@ int dvgo_brick_accumulate(const int32_t* brick_off, const int32_t* extra_off, co
   hipStream_t s = (hipStream_t)stream;
 #define DVGO_BRICK_ACC(CC)                                                                                        \
   do {                                                                                                            \
-    if (adam) brick_accumulate_kernel<CC, 1><<<blocks, 256, 0, s>>>(brick_off, extra_off, slot_off, extra_brick, arrive, scratch, \
+    if (adam) brick_accumulate_kernel<CC, 1><<<blocks, 256, 0, s>>>(brick_off, extra_off, active, extra_brick, arrive, scratch, \
                                                                      (const int4*)recs, rays_start, rays_dir,             \
                                                                      grad_feat, G, grad_k0, grad_density, A);             \
-    else brick_accumulate_kernel<CC, 0><<<blocks, 256, 0, s>>>(brick_off, extra_off, slot_off, extra_brick, arrive, scratch,   \
+    else brick_accumulate_kernel<CC, 0><<<blocks, 256, 0, s>>>(brick_off, extra_off, active, extra_brick, arrive, scratch,   \
                                                                 (const int4*)recs, rays_start, rays_dir,                  \
                                                                 grad_feat, G, grad_k0, grad_density, A);                  \
   } while (0)

@@ -159,7 +159,7 @@ class _FusedMarch(torch.autograd.Function):
             if bricks:
                 nb = L.lib().dvgo_n_bricks(X, Y, Z)
                 brick_cnt = torch.zeros(nb, dtype=torch.int32, device=dev)
-                brick_off = torch.empty((3, nb + 1), dtype=torch.int32, device=dev)    # list offsets, extra items, scratch tiles
+                brick_off = torch.empty((3, nb + 1), dtype=torch.int32, device=dev)    # list offsets, extra items, non-empty bricks
                 brick_cur = torch.empty(nb, dtype=torch.int32, device=dev)
                 # heavy bricks: extra work items <= entries / slice, entries <= 8 per record slot (the slice tables are
                 # built for up to 2^28 entries; render-sized batches beyond that run one workgroup per brick)
@@ -255,7 +255,7 @@ class _FusedMarch(torch.autograd.Function):
                 # heavy bricks run as several work items (slices of the list) that meet in scratch tiles
                 if extra_brick is not None:
                     n_extra_max = min(extra_brick.shape[0], E // slice_len)
-                    tiles = torch.empty((2 * (E // slice_len) + 2, 512 * ((C + 4) // 4 * 4)), dtype=torch.float32, device=dev)
+                    tiles = torch.empty((2 * n_extra_max + 1, 512 * ((C + 4) // 4 * 4)), dtype=torch.float32, device=dev)
                     items = (ptr(brick_off[0]), ptr(brick_off[1]), ptr(brick_off[2]), ptr(extra_brick), ptr(arrive),
                              ptr(tiles), _i64(n_extra_max), _int(slice_len))
                 else:

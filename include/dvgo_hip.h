@@ -304,22 +304,22 @@ int dvgo_march_density_bwd(const dvgo_rec2_t* rec2, const int32_t* n2, const int
 int dvgo_n_bricks(int X, int Y, int Z);
 int dvgo_brick_slice(void);     /* default slice_len: entries per work item of dvgo_brick_accumulate (heavy bricks are cut
                                  * into slices); the scan and the accumulation of one step must be given the same value (>= 256) */
-/* counts [n] -> offsets [n+1] + fill cursors [n].  With extra_off / slot_off [n+1] and extra_brick (all or none; then the
- * total must stay below 2^28 entries) also the slice tables of dvgo_brick_accumulate: a brick with more than slice_len
- * entries runs as ceil(count / slice_len) work items -- its own plus EXTRA ones appended behind the bricks
- * (extra_off[n] = their number <= E / slice_len, extra_brick[x] = the brick of extra item x), which meet in scratch tiles
- * (slot_off: first tile of each sliced brick, slot_off[n] <= 2 E / slice_len) -- and brick_cnt is CLEARED: it becomes the
- * arrival counter array of the slices. */
+/* counts [n] -> offsets [n+1] + fill cursors [n].  With extra_off / active [n+1] and extra_brick (all or none; then
+ * n < 2^18 and the total must stay below 2^28 entries) also the work tables of dvgo_brick_accumulate:
+ *   - a brick with more than slice_len entries runs as ceil(count / slice_len) work items -- its own plus EXTRA ones
+ *     appended behind the bricks (extra_off[n] = their number <= E / slice_len, extra_brick[x] = the brick of extra item x);
+ *   - active[0 .. active[n]) = the non-empty bricks in brick order;
+ *   - brick_cnt is CLEARED: it becomes the arrival counter array of the slices. */
 int dvgo_brick_scan(int32_t* brick_cnt, int n_bricks, int32_t* brick_off, int32_t* brick_cursor, int32_t* extra_off,
-                    int32_t* slot_off, int32_t* extra_brick /* [n_extra_max] */, int n_extra_max, int slice_len, void* stream);
+                    int32_t* active, int32_t* extra_brick /* [n_extra_max] */, int n_extra_max, int slice_len, void* stream);
 /* the ray scan (n3 [n_rays] -> off3 [n_rays + 1], int64) and dvgo_brick_scan in one launch; brick_cnt == NULL: rays only */
 int dvgo_march_scans(const int32_t* n3, int64_t n_rays, int64_t* off3, int32_t* brick_cnt, int n_bricks,
-                     int32_t* brick_off, int32_t* brick_cursor, int32_t* extra_off, int32_t* slot_off, int32_t* extra_brick,
+                     int32_t* brick_off, int32_t* brick_cursor, int32_t* extra_off, int32_t* active, int32_t* extra_brick,
                      int n_extra_max, int slice_len, void* stream);
-/* extra_off == NULL: one workgroup per brick, whatever its list length.  Else the slice tables of dvgo_brick_scan,
- * `arrive` = the cleared counters, `scratch` = slot_off[n] tiles of 512 * round_up(C + 1, 4) floats, n_extra_max = a
+/* extra_off == NULL: one workgroup per brick, whatever its list length.  Else the work tables of dvgo_brick_scan,
+ * `arrive` = the cleared counters, `scratch` = 2 * n_extra_max tiles of 512 * round_up(C + 1, 4) floats, n_extra_max = a
  * host-side upper bound of extra_off[n] (the launch is ceil8(n_bricks) + n_extra_max workgroups). */
-int dvgo_brick_accumulate(const int32_t* brick_off, const int32_t* extra_off, const int32_t* slot_off,
+int dvgo_brick_accumulate(const int32_t* brick_off, const int32_t* extra_off, const int32_t* active,
                           const int32_t* extra_brick, int32_t* arrive, float* scratch, int64_t n_extra_max, int slice_len,
                           const void* recs, const float* rays_start, const float* rays_dir,
                           float stepdist, const float* xyz_min, const float* xyz_max, const float* grad_feat,
