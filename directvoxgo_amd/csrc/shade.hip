@@ -22,6 +22,8 @@
 // Layer 3 (3 outputs) is 192 VALU FMAs per lane plus one cross-half add.
 #include "common.h"
 
+#include <type_traits>
+
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 static int g_shade_experiment = 0;   // timing experiments only (tools/): bit 0 = skip G1/G2 stores in shade_bwd
@@ -566,6 +568,310 @@ shade_wgrad_kernel(const float* __restrict__ G1, const float* __restrict__ gz, c
   }
 }
 
+// ----------------------------------------------------------------------------------
+// The same contraction, software-pipelined: two workgroups per CU, each walking 16-row tiles through a double buffer.
+// Everything a tile needs -- the three operand tiles, the view-dependent feature columns, the ray's view embedding
+// (gathered 4 bytes per lane), gz and the layer-2 sign words -- travels global -> LDS by LDS-DMA through buffer
+// descriptors (lane-constant offsets, the tile as the scalar offset, rows past M arrive as zeros), issued one tile ahead
+// of its use; the ray ids the embedding gather needs at issue time travel the same way two tiles further ahead, so no
+// load with a register destination is in flight inside the loop.  One bare barrier per tile.
+// What bounds it (profiles/r2, s_memtime stamps): one wave per SIMD issues in order and does not issue its own VALU /
+// LDS work under its own MFMAs, so a k-step costs its five MFMAs (74 cycles each at the sustained clock,
+// tools/micro/mfma_shape) PLUS its ~30 other instructions; the second workgroup's wave on the SIMD fills those slots
+// and the tile-boundary bubble (barrier, DMA issue, first operand read).
+// ----------------------------------------------------------------------------------
+// LDS reads the compiler must not see: hipcc orders every ds_read it knows of behind ALL LDS-DMA in flight (vmcnt(0)),
+// i.e. behind the groups that are meant to stay in flight.  Address = byte offset into LDS, OFF = immediate offset.
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
+}
+template <int OFF> __device__ __forceinline__ float lds_f32(unsigned a) {
+  float v; asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF)); return v;
+}
+template <int OFF> __device__ __forceinline__ unsigned lds_u32(unsigned a) {
+  unsigned v; asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF)); return v;
+}
+typedef float dvgo_f32x4 __attribute__((ext_vector_type(4)));
+template <int OFF> __device__ __forceinline__ dvgo_f32x4 lds_f32x4(unsigned a) {
+  dvgo_f32x4 v; asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF)); return v;
+}
+template <int I, int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+
+template <int WIDTH>
+struct ShadeWgradRing {
+  static constexpr int NB = 2, NR = 4, TR = 16;
+  float g1[NB][TR][WIDTH], h1[NB][TR][WIDTH], h2[NB][TR][WIDTH];
+  float xf[NB][TR][16];                // the view-dependent feature columns (n_view <= 16), zero-padded
+  float xe[NB][TR][32];                // the ray's view embedding (E <= 32), zero-padded
+  float gz[NB][TR][4];                 // [row][0..2], [3] = 0
+  unsigned int m2[NB][TR][4];          // layer-2 sign words [lane half][32-bit half]
+  unsigned int rid[NR][64];            // [row] ray of the tile's rows (first TR words; one DMA instruction writes 64)
+};
+
+// the operands of one k-step (rows 2s, 2s + 1 of a tile) as this lane reads them
+template <int T>
+struct WgradOperands {
+  dvgo_f32x4 gq, xa, xb;
+  unsigned mw;
+  float g1v, h1v[T], xv, h2v;
+};
+
+#define DVGO_OOB 0x80000000u           // a byte offset past every buffer below: the DMA then writes zeros
+
+template <int WIDTH>
+__global__ void __launch_bounds__(2 * WIDTH, 2)      // two workgroups per CU: at most 256 registers per lane
+shade_wgrad_ring_kernel(const float* __restrict__ G1, const float* __restrict__ gz, const unsigned int* __restrict__ masks,
+                        const float* __restrict__ W3, const float* __restrict__ H1, const float* __restrict__ H2,
+                        const float* __restrict__ feat, int C, int c_view0, int n_view, const float* __restrict__ emb, int E,
+                        const int64_t* __restrict__ ray_id, int64_t M_cap, const int64_t* __restrict__ m_dev,
+                        float* __restrict__ part /* [gridDim][WIDTH*WIDTH + WIDTH*64 + 32*WIDTH + 3*WIDTH] */) {
+#if defined(__HIP_DEVICE_COMPILE__)   // buffer descriptors are device-only types: the host pass needs the launch stub only
+  // (everything the DMA descriptors, scalar offsets and LDS targets are built from must be PROVABLY wave-uniform, or the
+  // compiler wraps each DMA in a readfirstlane loop: the row count comes from memory, the wave index from threadIdx)
+  int64_t M;
+  {
+    const int64_t m = m_dev ? (*m_dev < M_cap ? *m_dev : M_cap) : M_cap;
+    M = ((int64_t)__builtin_amdgcn_readfirstlane((int)(m >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)m);
+  }
+  using Ring = ShadeWgradRing<WIDTH>;
+  constexpr int T = WIDTH / 32, NW = T, NB = Ring::NB, NR = Ring::NR, TR = Ring::TR;      // NW waves
+  static_assert(T == 4 || T == 2, "widths 128 and 64");
+  constexpr int LPR = WIDTH / 4;             // lanes per operand row in a 16-byte DMA instruction
+  constexpr int RPI = 64 / LPR;              // rows per such instruction (1 KB)
+  constexpr int IPW = TR / RPI / NW;         // bulk instructions per wave, operand and tile
+  constexpr int FPW = 4 / NW, EPW = 8 / NW;  // feature / embedding gather instructions per wave and tile
+  static_assert(IPW == 2 && NB == 2, "double buffer: the wait at the top of a tile is vmcnt(0)");
+  __shared__ __attribute__((aligned(16))) Ring L;
+  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, j = lane & 31;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  f32x16 aW2[T], aW1;
+  float vW3[3] = {0.0f, 0.0f, 0.0f}, vW1[8], sgz[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) aW2[t][r] = 0.0f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) aW1[r] = 0.0f;
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) vW1[kk] = 0.0f;
+  float sb1 = 0.0f, sb2 = 0.0f;
+  const float w30 = W3[32 * w + j], w31 = W3[WIDTH + 32 * w + j], w32 = W3[2 * WIDTH + 32 * w + j];
+  const int m_idx = 2 * ((j >> 2) & 1) + (w >> 1), m_bit = 16 * (w & 1) + (j & 3) + 4 * (j >> 3);
+  const int d_in = n_view + E;
+  const int n_tiles = (int)((M + TR - 1) / TR);        // 32-bit scalar arithmetic from here on (M * WIDTH * 4 < 2^31)
+  auto tile_of = [&](int k) { return (int)blockIdx.x + k * (int)gridDim.x; };
+
+  // Buffer descriptors sized by the M valid rows: a row past M (the tail of the last tile, the run-ahead tiles past the
+  // end) is out of range and arrives as zeros -- no clamping, no masking at operand read, and the operation count per
+  // group never varies.  Per-lane byte offsets are constants of the lane; the tile enters as the scalar offset.
+  const unsigned rows_b = (unsigned)(M * WIDTH * 4);
+  const auto bG1 = __builtin_amdgcn_make_buffer_rsrc((void*)G1, 0, rows_b, 0x00020000);
+  const auto bH1 = __builtin_amdgcn_make_buffer_rsrc((void*)H1, 0, rows_b, 0x00020000);
+  const auto bH2 = __builtin_amdgcn_make_buffer_rsrc((void*)H2, 0, rows_b, 0x00020000);
+  const auto bF = __builtin_amdgcn_make_buffer_rsrc((void*)feat, 0, (unsigned)(M * C * 4), 0x00020000);
+  const auto bE = __builtin_amdgcn_make_buffer_rsrc((void*)emb, 0, DVGO_OOB, 0x00020000);     // ray count not known here
+  const auto bGz = __builtin_amdgcn_make_buffer_rsrc((void*)gz, 0, (unsigned)(M * 12), 0x00020000);
+  const auto bM = __builtin_amdgcn_make_buffer_rsrc((void*)masks, 0, (unsigned)(M * 32), 0x00020000);
+  const auto bR = __builtin_amdgcn_make_buffer_rsrc((void*)ray_id, 0, (unsigned)(M * 8), 0x00020000);
+  unsigned vo_bulk[IPW], vo_f[FPW], vo_ecol[EPW];
+  int e_row[EPW];
+#pragma unroll
+  for (int i = 0; i < IPW; ++i) vo_bulk[i] = (unsigned)(((IPW * w + i) * RPI + lane / LPR) * WIDTH * 4 + 16 * (lane % LPR));
+#pragma unroll
+  for (int i = 0; i < FPW; ++i) {
+    const int e = 64 * (w + NW * i) + lane, row = e >> 4, col = e & 15;
+    vo_f[i] = col < n_view ? (unsigned)((row * C + c_view0 + col) * 4) : DVGO_OOB;
+  }
+#pragma unroll
+  for (int i = 0; i < EPW; ++i) {
+    const int e = 64 * (w + NW * i) + lane, col = e & 31;
+    e_row[i] = e >> 5;
+    vo_ecol[i] = col < E ? (unsigned)(col * 4) : DVGO_OOB;
+  }
+  const unsigned vo_gz = (lane & 3) < 3 ? (unsigned)(((lane >> 2) * 3 + (lane & 3)) * 4) : DVGO_OOB;
+  const unsigned vo_m2 = (unsigned)(((lane >> 2) * 8 + 4 + (lane & 3)) * 4);
+  const unsigned vo_rid = (unsigned)((lane & (TR - 1)) * 8);                         // rays < 2^31: the low words
+
+  // group(t) = the DMA of tile t (its embedding gather reads the tile's ray ids from LDS) + the ray ids of tile t + 2
+  auto issue = [&](int t) {
+    const int sl = t & (NB - 1);
+    const unsigned r0 = (unsigned)__builtin_amdgcn_readfirstlane(tile_of(t) * TR);
+#pragma unroll
+    for (int i = 0; i < IPW; ++i) {
+      const int rl = (IPW * w + i) * RPI;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(bG1, (dvgo_lptr_t)&L.g1[sl][rl][0], 16, vo_bulk[i], r0 * (WIDTH * 4), 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(bH1, (dvgo_lptr_t)&L.h1[sl][rl][0], 16, vo_bulk[i], r0 * (WIDTH * 4), 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(bH2, (dvgo_lptr_t)&L.h2[sl][rl][0], 16, vo_bulk[i], r0 * (WIDTH * 4), 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < FPW; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(bF, (dvgo_lptr_t)(&L.xf[sl][0][0] + 64 * (w + NW * i)), 4, vo_f[i], r0 * (unsigned)(C * 4), 0, 0);
+    unsigned rids[EPW];
+#pragma unroll
+    for (int i = 0; i < EPW; ++i) rids[i] = lds_u32<0>(lds_addr(&L.rid[t & (NR - 1)][e_row[i]]));
+    if constexpr (EPW == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rids[0]), "+v"(rids[1]));
+    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rids[0]), "+v"(rids[1]), "+v"(rids[EPW - 2]), "+v"(rids[EPW - 1]));
+#pragma unroll
+    for (int i = 0; i < EPW; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(bE, (dvgo_lptr_t)(&L.xe[sl][0][0] + 64 * (w + NW * i)), 4,
+                                               vo_ecol[i] + rids[i] * (unsigned)(E * 4), 0, 0, 0);
+    // gz, the sign words and the ray ids of tile t + 2: one instruction each, spread over the waves (the last repeated)
+    const unsigned rn = (unsigned)__builtin_amdgcn_readfirstlane(tile_of(t + 2) * TR);
+    const int rsl = (t + 2) & (NR - 1);
+    auto small = [&](int which) {
+      if (which == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(bGz, (dvgo_lptr_t)&L.gz[sl][0][0], 4, vo_gz, r0 * 12u, 0, 0);
+      else if (which == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(bM, (dvgo_lptr_t)&L.m2[sl][0][0], 4, vo_m2, r0 * 32u, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(bR, (dvgo_lptr_t)&L.rid[rsl][0], 4, vo_rid, rn * 8u, 0, 0);
+    };
+    if constexpr (NW == 4) {
+      small(w < 2 ? w : 2);
+    } else {
+      small(w);
+      small(2);
+    }
+  };
+
+  // this lane's operand addresses in slot 0, row h
+  const unsigned a_gz = lds_addr(&L.gz[0][h][0]), a_mw = lds_addr(&L.m2[0][h][m_idx]);
+  const unsigned a_g1 = lds_addr(&L.g1[0][h][32 * w + j]), a_h1 = lds_addr(&L.h1[0][h][j]);
+  const unsigned a_h2 = lds_addr(&L.h2[0][h][32 * w + j]);
+  // X column j: a feature column or an embedding column; the trailing columns 32 .. 39 are embedding columns
+  // 32 - n_view .. (the host routes shapes with d_in > 32 here only when that is a 16-byte boundary)
+  const bool x_in_f = j < n_view;
+  const unsigned a_x = x_in_f ? lds_addr(&L.xf[0][h][j]) : lds_addr(&L.xe[0][h][j - n_view]);
+  const unsigned x_slot = x_in_f ? (unsigned)(TR * 16 * 4) : (unsigned)(TR * 32 * 4), x_step = x_in_f ? 128u : 256u;
+  const bool trail = d_in > 32;
+  const unsigned a_xa = lds_addr(&L.xe[0][h][trail ? 32 - n_view : 0]);
+  constexpr unsigned SLOT_ROWS = TR * WIDTH * 4;                                   // bytes per slot
+  using Ops = WgradOperands<T>;
+  auto wait_ops = [&](Ops& o) {
+    if constexpr (T == 4)
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o.gq), "+v"(o.xa), "+v"(o.xb), "+v"(o.mw), "+v"(o.g1v), "+v"(o.h1v[0]),
+                   "+v"(o.h1v[1]), "+v"(o.h1v[2]), "+v"(o.h1v[3]), "+v"(o.xv), "+v"(o.h2v));
+    else
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o.gq), "+v"(o.xa), "+v"(o.xb), "+v"(o.mw), "+v"(o.g1v), "+v"(o.h1v[0]),
+                   "+v"(o.h1v[1]), "+v"(o.xv), "+v"(o.h2v));
+  };
+
+  // the ray ids of the first two tiles by hand, then group 0
+  if (tid < 64) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int64_t row = (int64_t)tile_of(t) * TR + (tid & (TR - 1));
+      L.rid[t][tid] = row < M ? (unsigned int)ray_id[row] : 0u;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < NB - 1; ++t) issue(t);
+  for (int k = 0; tile_of(k) < n_tiles; ++k) {
+    const int sl = k & (NB - 1);
+    // behind the barrier every wave's share of tile k has landed and every wave is done with tile k - 1, whose slot
+    // group k + 1 overwrites (its ray ids came with group k - 1)
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    issue(k + NB - 1);
+    const unsigned b_gz = a_gz + sl * (TR * 16), b_mw = a_mw + sl * (TR * 16), b_g1 = a_g1 + sl * SLOT_ROWS;
+    const unsigned b_h1 = a_h1 + sl * SLOT_ROWS, b_h2 = a_h2 + sl * SLOT_ROWS;
+    const unsigned b_xa = a_xa + sl * (TR * 32 * 4);
+    unsigned b_x = a_x + sl * x_slot;                   // advances by two rows per k-step (row length depends on the lane)
+    Ops ops[2];
+    float a2s[2], a1s[2];
+    auto read_ops = [&](auto Sc, Ops& o) {
+      constexpr int s = decltype(Sc)::value;
+      o.gq = lds_f32x4<32 * s>(b_gz);                  // broadcast
+      o.mw = lds_u32<32 * s>(b_mw);
+      o.g1v = lds_f32<8 * WIDTH * s>(b_g1);
+      static_for<0, T>([&](auto Tc) { constexpr int t = decltype(Tc)::value; o.h1v[t] = lds_f32<8 * WIDTH * s + 128 * t>(b_h1); });
+      o.xv = lds_f32<0>(b_x);
+      b_x += x_step;
+      o.xa = lds_f32x4<256 * s>(b_xa);                 // broadcast; zero past d_in
+      o.xb = lds_f32x4<256 * s + 16>(b_xa);
+      o.h2v = lds_f32<8 * WIDTH * s>(b_h2);
+    };
+    // the A operands of a step: G2 rebuilt from gz and the layer-2 sign bit (zeros on rows past M), G1 as read
+    auto prep = [&](const Ops& o, float& a2, float& a1) {
+      const float g2v = fmaf(w32, o.gq.z, fmaf(w31, o.gq.y, w30 * o.gq.x));
+      a2 = ((o.mw >> m_bit) & 1u) ? g2v : 0.0f;
+      a1 = o.g1v;
+    };
+    read_ops(std::integral_constant<int, 0>{}, ops[0]);
+    wait_ops(ops[0]);
+    prep(ops[0], a2s[0], a1s[0]);
+    // One wave per SIMD issues in order, and an MFMA enters the pipe 64 cycles after the previous one: whatever follows a
+    // run of MFMAs in program order waits for all of them.  So a step is laid out around its five MFMAs, the gaps between
+    // them holding (pinned by sched_barrier) the NEXT step's operand reads -- issued behind the first MFMA, waited for
+    // behind the third, turned into A operands behind the fourth -- and this step's bias / dW3 / trailing-column FMAs.
+    // Between the last MFMA of a step and the first of the next there is nothing.
+    static_for<0, TR / 2>([&](auto Sc) {
+      constexpr int s = decltype(Sc)::value;
+      constexpr bool more = s + 1 < TR / 2;
+      Ops& cur = ops[s & 1];
+      Ops& nxt = ops[(s + 1) & 1];
+      const float a2 = a2s[s & 1], a1 = a1s[s & 1];
+      aW2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, cur.h1v[0], aW2[0], 0, 0, 0);
+      if constexpr (more) read_ops(std::integral_constant<int, s + 1>{}, nxt);
+      sb2 += a2; sb1 += a1;
+      sgz[0] += cur.gq.x; sgz[1] += cur.gq.y; sgz[2] += cur.gq.z;
+      __builtin_amdgcn_sched_barrier(0);
+      aW2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, cur.h1v[1], aW2[1], 0, 0, 0);
+      vW1[0] = fmaf(a1, cur.xa.x, vW1[0]); vW1[1] = fmaf(a1, cur.xa.y, vW1[1]); vW1[2] = fmaf(a1, cur.xa.z, vW1[2]);
+      vW1[3] = fmaf(a1, cur.xa.w, vW1[3]);
+      vW3[0] = fmaf(cur.gq.x, cur.h2v, vW3[0]); vW3[1] = fmaf(cur.gq.y, cur.h2v, vW3[1]); vW3[2] = fmaf(cur.gq.z, cur.h2v, vW3[2]);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (T == 4) aW2[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, cur.h1v[2], aW2[2], 0, 0, 0);
+      vW1[4] = fmaf(a1, cur.xb.x, vW1[4]); vW1[5] = fmaf(a1, cur.xb.y, vW1[5]); vW1[6] = fmaf(a1, cur.xb.z, vW1[6]);
+      vW1[7] = fmaf(a1, cur.xb.w, vW1[7]);
+      if constexpr (more) wait_ops(nxt);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (T == 4) aW2[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, cur.h1v[3], aW2[3], 0, 0, 0);
+      if constexpr (more) prep(nxt, a2s[(s + 1) & 1], a1s[(s + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      aW1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, cur.xv, aW1, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the run-ahead groups: nothing may land after the workgroup is gone
+  // D[row = (r&3) + 8*(r>>2) + 4*h][col = j]
+  float* p = part + (int64_t)blockIdx.x * (WIDTH * WIDTH + WIDTH * 64 + 32 * WIDTH + 3 * WIDTH);
+  float* pW2 = p;                          // [WIDTH out][WIDTH in]
+  float* pW1 = pW2 + WIDTH * WIDTH;        // [WIDTH out][64]
+  float* pW3 = pW1 + WIDTH * 64;           // [32 (c padded)][WIDTH], rows 0..2 written
+  float* pb = pW3 + 32 * WIDTH;            // [3][WIDTH]: db1, db2, db3 (first 3 entries)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+#pragma unroll
+    for (int t = 0; t < T; ++t) pW2[(32 * w + i) * WIDTH + 32 * t + j] = aW2[t][r];
+    pW1[(32 * w + i) * 64 + j] = aW1[r];
+  }
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) {         // VALU parts: lanes j and j + 32 hold the even / odd rows
+    const float v = vW1[kk] + __shfl_xor(vW1[kk], 32);
+    if (h == 0) pW1[(32 * w + j) * 64 + 32 + kk] = (trail && 32 + kk < d_in) ? v : 0.0f;
+  }
+  if (h == 0) {
+#pragma unroll
+    for (int kk = 8; kk < 32; ++kk) pW1[(32 * w + j) * 64 + 32 + kk] = 0.0f;
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float v = vW3[c] + __shfl_xor(vW3[c], 32);
+    if (h == 0) pW3[c * WIDTH + 32 * w + j] = v;
+    sgz[c] += __shfl_xor(sgz[c], 32);
+  }
+  sb1 += __shfl_xor(sb1, 32); sb2 += __shfl_xor(sb2, 32);
+  if (h == 0) {
+    pb[32 * w + j] = sb1;
+    pb[WIDTH + 32 * w + j] = sb2;
+    if (j < 8) pb[2 * WIDTH + 8 * w + j] = (w == 0 && j < 3) ? sgz[j] : 0.0f;   // db3 = entries [0,3) (+ [8,11): zero here)
+    if (T == 2 && j >= 16) pb[2 * WIDTH + 16 * w + j] = 0.0f;
+  }
+#endif
+}
+#undef DVGO_OOB
+
 // sum of the per-workgroup partials: [n_parts][n] -> [n].  blockIdx.y takes a slice of the parts so that a few
 // thousand wavefronts stream the 60 MB (one column block alone would leave the chip idle and latency-bound:
 // 124 us -> ~20 us); slices meet in `out` (zeroed by the caller) with one float atomic per element.
@@ -667,6 +973,15 @@ int dvgo_shade_wgrad(const float* G1, const float* gz, const uint64_t* masks, co
     if (n_parts > 256) n_parts = 256;       // one 8-wave workgroup per CU (141 KB of LDS)
     const int rc = dvgo_shade_wgrad_x3(G1, gz, masks, W3, H1, H2, feat, C, emb, E, ray_id, M, m_dev, width, diffuse, n_parts, part, stream);
     if (rc != 0) return rc;
+  } else if (!(g_shade_variant & 8) && n_view <= 16 && E <= 32 && (n_view + E <= 32 || (n_view % 4 == 0 && n_view >= 8)) &&
+             M * width * 4 < ((int64_t)1 << 31) && M * C * 4 < ((int64_t)1 << 31)) {
+    if (n_parts > 512) n_parts = 512;       // two workgroups per CU (55 KB of LDS each)
+    if (width == 128)
+      shade_wgrad_ring_kernel<128><<<n_parts, 256, 0, (hipStream_t)stream>>>(
+          G1, gz, (const unsigned int*)masks, W3, H1, H2, feat, C, c_view0, n_view, emb, E, ray_id, M, m_dev, part);
+    else
+      shade_wgrad_ring_kernel<64><<<n_parts, 128, 0, (hipStream_t)stream>>>(
+          G1, gz, (const unsigned int*)masks, W3, H1, H2, feat, C, c_view0, n_view, emb, E, ray_id, M, m_dev, part);
   } else if (width == 128)
     shade_wgrad_kernel<128><<<n_parts, 256, 0, (hipStream_t)stream>>>(
         G1, gz, (const unsigned int*)masks, W3, H1, H2, feat, C, c_view0, n_view, emb, E, ray_id, M, m_dev, part);

@@ -13,7 +13,7 @@ import torch.nn as nn
 from . import _lib as L
 from ._lib import _i64, _int, ptr, stream_of
 
-N_PARTS = 512     # max workgroups (= partial sums) of the weight-gradient kernel: two per CU (74 KB of LDS each)
+N_PARTS = 512     # max workgroups (= partial sums) of the weight-gradient kernel: two per CU (55 KB of LDS each)
 
 
 class defer_wgrad:
