@@ -5,7 +5,7 @@ saved-tensor conventions) on top of the HIP kernels:
 
   Raw2Alpha, Alphas2Weights   lib/dvgo.py:618-660
   MaskCache                   lib/dvgo.py:583-613
-  grid_sample / DenseGrid     lib/dvgo.py:312-328 (grid_sampler -> F.grid_sample + its backward)
+  grid_sample                 lib/dvgo.py:312-328 (grid_sampler -> F.grid_sample + its backward)
   segment_coo                 torch_scatter.segment_coo(src, index, out, reduce='sum')
   total_variation_add_grad    lib/cuda/total_variation.cpp:16-24
 """
@@ -114,53 +114,6 @@ def grid_sample(grid, xyz, xyz_min, xyz_max):
     if out.shape[-1] == 1:
         out = out.squeeze(-1)
     return out
-
-
-class DenseGrid(nn.Module):
-    """Dense voxel grid with trilinear lookup -- the build-side name for what the reference
-    spells ``nn.Parameter(torch.zeros([1, C, *world_size]))`` + ``grid_sampler``
-    (lib/dvgo.py:68,86,94,312-328).
-
-    The parameter keeps the reference's logical shape [1,C,X,Y,Z] (so ``state_dict`` and
-    checkpoints round-trip) but, for C > 1, is stored channels-last (``torch.channels_last_3d``):
-    the C values of a voxel corner are contiguous, which is what the gfx950 kernels want.
-    """
-
-    def __init__(self, channels, world_size, xyz_min, xyz_max, channels_last=True):
-        super().__init__()
-        self.channels = int(channels)
-        self.channels_last = bool(channels_last)
-        self.register_buffer('xyz_min', torch.as_tensor(xyz_min, dtype=torch.float32).clone())
-        self.register_buffer('xyz_max', torch.as_tensor(xyz_max, dtype=torch.float32).clone())
-        self.grid = nn.Parameter(self._alloc([1, self.channels, *[int(v) for v in world_size]]))
-
-    def _alloc(self, shape, like=None):
-        g = torch.zeros(shape, dtype=torch.float32, device=None if like is None else like.device)
-        if self.channels_last and shape[1] > 1:
-            g = g.contiguous(memory_format=torch.channels_last_3d)
-        return g
-
-    def forward(self, xyz):
-        return grid_sample(self.grid, xyz, self.xyz_min, self.xyz_max)
-
-    @torch.no_grad()
-    def scale_volume_grid(self, new_world_size):
-        """lib/dvgo.py:235-239: F.interpolate(..., mode='trilinear', align_corners=True)."""
-        new_world_size = tuple(int(v) for v in new_world_size)
-        if self.channels == 0:
-            data = torch.zeros([1, 0, *new_world_size], device=self.grid.device)
-        else:
-            data = F.interpolate(self.grid.data.contiguous(), size=new_world_size, mode='trilinear',
-                                 align_corners=True)
-        if self.channels_last and self.channels > 1:
-            data = data.contiguous(memory_format=torch.channels_last_3d)
-        self.grid = nn.Parameter(data)
-
-    def total_variation_add_grad(self, wx, wy, wz, dense_mode):
-        total_variation_add_grad(self.grid, self.grid.grad, wx, wy, wz, dense_mode)
-
-    def extra_repr(self):
-        return f'channels={self.channels}, world_size={tuple(self.grid.shape[2:])}, channels_last={self.channels_last}'
 
 
 class MaskCache(nn.Module):

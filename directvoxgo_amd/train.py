@@ -277,6 +277,29 @@ class TrainStep:
             works.append(dist.all_gather_into_tensor(fp, fp[lo:hi], group=self.pg, async_op=True))
         return works
 
+    @torch.no_grad()
+    def gather_optimizer_state(self):
+        """Data-parallel runs with the sharded update: every rank has only ever updated the moments of the X-slab it
+        owns.  Before `checkpoint.save_checkpoint` (or any other reader of `optimizer.state_dict()`), all-gather the slabs
+        in place so that every rank holds the complete `exp_avg` / `exp_avg_sq` of both grids -- the state a single
+        process would have written (run.py:420-437).  No-op on one rank or when the grids are not sharded."""
+        if not (self.shard_grids and self.world > 1 and hasattr(self.optimizer, 'step_shard')):
+            return False
+        rank = dist.get_rank(self.pg)
+        done = False
+        for p in (getattr(self.model, 'density', None), getattr(self.model, 'k0', None)):
+            st = self.optimizer.state.get(p) if isinstance(p, nn.Parameter) else None
+            if not st or p.dim() != 5 or p.shape[2] % self.world != 0:
+                continue
+            for key in ('exp_avg', 'exp_avg_sq'):
+                flat = flat_view(st[key])
+                if flat is None or st[key].stride() != p.stride():
+                    raise RuntimeError(f'gather_optimizer_state: {key} is not laid out like its parameter')
+                n = flat.numel() // self.world
+                dist.all_gather_into_tensor(flat, flat[rank * n:(rank + 1) * n].clone(), group=self.pg)
+            done = True
+        return done
+
     def _sample_count(self, res):
         """Number of surviving samples of the step, without waiting for it: exact when the forward read it back anyway,
         else the last value that has arrived from the device (copied asynchronously into pinned memory every step)."""

@@ -10,6 +10,7 @@ import os
 import socket
 
 import pytest
+import numpy as np
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -95,7 +96,7 @@ class TorchMaskedAdam(torch.optim.Optimizer):
                   g['lr'], mode=1 if g.get('skip_zero_grad') else 0)
 
 
-def run_steps(model, batch, rank, world, n_steps=3, mode='dense'):
+def run_steps(model, batch, rank, world, n_steps=3, mode='dense', out=None):
     cfg = dict(FINE_TRAIN, weight_entropy_last=0.01, weight_rgbper=0.05)
     if mode in ('sharded', 'sharded_off'):
         # Adam with the masked rule on the grids, the sharded update on (reduce-scatter -> slab Adam -> all-gather)
@@ -126,7 +127,14 @@ def run_steps(model, batch, rank, world, n_steps=3, mode='dense'):
         assert step.sharded_steps == n_steps                    # the slab path really ran
     if mode == 'sharded_off':
         assert step.sharded_steps == 0
+    if out is not None:
+        out['step'] = step
     return torch.stack(losses)
+
+
+def _moments(model, step):
+    return {f'{name}.{key}': step.optimizer.state[p][key].detach().numpy().copy()
+            for name, p in (('density', model.density), ('k0', model.k0)) for key in ('exp_avg', 'exp_avg_sq')}
 
 
 def _worker(rank, world, port, q, mode='dense'):
@@ -135,11 +143,16 @@ def _worker(rank, world, port, q, mode='dense'):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     torch.set_num_threads(1)
     model = ToyModel()
-    losses = run_steps(model, make_batch(32), rank, world, mode=mode)
+    out = {}
+    losses = run_steps(model, make_batch(32), rank, world, mode=mode, out=out)
     dist.all_reduce(losses)           # per-rank shares of the global loss add up to it
+    moments = None
+    if mode == 'sharded':             # what a checkpoint of a data-parallel run needs: every rank's slab of the moments
+        assert out['step'].gather_optimizer_state()
+        moments = _moments(model, out['step'])
     if rank == 0:
         # numpy: pickled by value (torch tensors would travel as shared-memory handles of a process about to exit)
-        q.put(({k: v.detach().numpy().copy() for k, v in model.state_dict().items()}, losses.numpy().copy()))
+        q.put(({k: v.detach().numpy().copy() for k, v in model.state_dict().items()}, losses.numpy().copy(), moments))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -158,20 +171,25 @@ def test_two_ranks_equal_one_process(mode):
     """`touched`: the grid gradients travel as the compacted union of the voxels either rank touched.
     `sharded`: reduce-scatter of the grid gradients, Adam on the owned X-slab only, all-gather of the parameters."""
     ref_model = ToyModel()
-    ref_losses = run_steps(ref_model, make_batch(32), 0, 1, mode=mode if mode.startswith('sharded') else 'dense')
+    ref_out = {}
+    ref_losses = run_steps(ref_model, make_batch(32), 0, 1, mode=mode if mode.startswith('sharded') else 'dense', out=ref_out)
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q, mode)) for r in range(2)]
     for p in procs:
         p.start()
-    sd, losses = q.get(timeout=100)
+    sd, losses, moments = q.get(timeout=100)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     assert torch.allclose(torch.from_numpy(losses), ref_losses, rtol=1e-5, atol=1e-7)
     for k, v in ref_model.state_dict().items():
         assert torch.allclose(torch.from_numpy(sd[k]), v, rtol=1e-5, atol=1e-6), k
+    if mode == 'sharded':             # gathered moments == the single process's: the checkpoint of the run is complete
+        for k, v in _moments(ref_model, ref_out['step']).items():
+            assert np.allclose(moments[k], v, rtol=1e-5, atol=1e-8), k
+            assert np.abs(moments[k]).sum() > 0
 
 
 def test_flat_view_of_channels_last_grid_is_a_view():

@@ -363,6 +363,16 @@ def _shade_vs_torch(M, diffuse, width, C, E):
     # summation order): that sample's feature gradient then differs as a whole row -- allow a handful of such rows
     a, b = gs[0].cpu().numpy(), gr[0].cpu().numpy()
     bad_rows = (~np.isclose(a, b, rtol=2e-4, atol=2e-5 * max(1.0, float(np.abs(b).max())))).any(1)
+    if bad_rows.sum() > max(1, M // 10000):
+        # which side flipped?  torch's fp32 GEMM picks its algorithm (and summation order) per call; a float64 evaluation
+        # of the same modules is the arbiter: a row only counts against the kernel if it is off against that as well
+        import copy
+        net64 = copy.deepcopy(net).double()
+        f64 = feat.detach().double().requires_grad_()
+        x64 = torch.cat([f64[:, 3:] if diffuse else f64, emb.double()[ray_id]], -1)
+        ref64 = torch.sigmoid(net64(x64) + (f64[:, :3] if diffuse else 0))
+        b64 = torch.autograd.grad(ref64, f64, go.double())[0].cpu().numpy()
+        bad_rows &= (~np.isclose(a, b64, rtol=2e-4, atol=2e-5 * max(1.0, float(np.abs(b64).max())))).any(1)
     assert bad_rows.sum() <= max(1, M // 10000), f'{bad_rows.sum()} rows of the feature gradient differ'
     for a, b in zip(gs[1:], gr[1:]):
         a, b = a.cpu().numpy(), b.cpu().numpy()
