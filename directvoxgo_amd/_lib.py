@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # DVGO_HIP_SO: another build of the same library (kernel A/B runs, tools/)
 SO_PATH = os.environ.get('DVGO_HIP_SO') or os.path.join(_HERE, 'csrc', 'libdvgo_hip.so')
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _lib = None
 

@@ -36,7 +36,8 @@ def build(force=False, verbose=True, extra_flags=()):
     procs = []
     for f in SOURCES:   # compile the translation units in parallel, then link
         o = os.path.join(CSRC, f.replace('.hip', '.o'))
-        cmd = [hipcc] + [x for x in FLAGS if x != '-shared'] + list(extra_flags) + ['-c', os.path.join(CSRC, f), '-o', o]
+        per_file = os.environ.get('DVGO_FLAGS_' + f.replace('.hip', '').upper(), '').split()   # e.g. DVGO_FLAGS_SHADE_X3='-mllvm ...'
+        cmd = [hipcc] + [x for x in FLAGS if x != '-shared'] + list(extra_flags) + per_file + ['-c', os.path.join(CSRC, f), '-o', o]
         if verbose:
             print(' '.join(cmd), flush=True)
         procs.append((cmd, subprocess.Popen(cmd)))

@@ -415,11 +415,14 @@ march_composite_bwd_kernel(const float* __restrict__ gout, const float* __restri
                            const float* __restrict__ rgb, const int64_t* __restrict__ ray_id, int64_t M_cap,
                            const int64_t* __restrict__ m_dev,
                            float* __restrict__ grad_weights, float* __restrict__ grad_rgb, int64_t n_rays, float bg,
-                           float* __restrict__ grad_last) {
+                           float* __restrict__ grad_last, int accumulate) {
   const int64_t M3 = m_dev ? (*m_dev < M_cap ? *m_dev : M_cap) : M_cap;      // sample count kept on the device (train.py)
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   // d rgb_marched / d alphainv_last = bg (lib/dvgo.py:559): the N-sized reduction rides on the first n_rays threads
-  if (grad_last != nullptr && i < n_rays) grad_last[i] = (gout[3 * i] + gout[3 * i + 1] + gout[3 * i + 2]) * bg;
+  // (accumulate: grad_rgb / grad_last already hold another consumer's gradient of the same tensors -- the loss's --
+  // and this launch adds to it, which saves the framework's two summation launches, the first of them over [M, 3])
+  if (grad_last != nullptr && i < n_rays)
+    grad_last[i] = (gout[3 * i] + gout[3 * i + 1] + gout[3 * i + 2]) * bg + (accumulate ? grad_last[i] : 0.0f);
   if (i >= M3) return;
   const int64_t r = ray_id[i];
   const float g0 = gout[3 * r], g1 = gout[3 * r + 1], g2 = gout[3 * r + 2];
@@ -427,9 +430,15 @@ march_composite_bwd_kernel(const float* __restrict__ gout, const float* __restri
   if (grad_weights)
     grad_weights[i] = fmaf(g2, rgb[3 * i + 2], fmaf(g1, rgb[3 * i + 1], g0 * rgb[3 * i]));
   if (grad_rgb) {
-    grad_rgb[3 * i + 0] = g0 * w;
-    grad_rgb[3 * i + 1] = g1 * w;
-    grad_rgb[3 * i + 2] = g2 * w;
+    if (accumulate) {
+      grad_rgb[3 * i + 0] = fmaf(g0, w, grad_rgb[3 * i + 0]);
+      grad_rgb[3 * i + 1] = fmaf(g1, w, grad_rgb[3 * i + 1]);
+      grad_rgb[3 * i + 2] = fmaf(g2, w, grad_rgb[3 * i + 2]);
+    } else {
+      grad_rgb[3 * i + 0] = g0 * w;
+      grad_rgb[3 * i + 1] = g1 * w;
+      grad_rgb[3 * i + 2] = g2 * w;
+    }
   }
 }
 
@@ -861,7 +870,7 @@ int dvgo_march_composite(const float* weights, const float* rgb, const int64_t* 
 
 int dvgo_march_composite_bwd(const float* grad_rgb_marched, const float* weights, const float* rgb,
                              const int64_t* ray_id, int64_t M3, const int64_t* m_dev, int64_t n_rays, float bg,
-                             float* grad_weights, float* grad_rgb, float* grad_last, void* stream) {
+                             float* grad_weights, float* grad_rgb, float* grad_last, int accumulate, void* stream) {
   if (M3 < 0 || n_rays < 0) return DVGO_EINVAL;
   const int64_t n_last = grad_last ? n_rays : 0;
   if (M3 == 0 && n_last == 0) return 0;
@@ -869,7 +878,7 @@ int dvgo_march_composite_bwd(const float* grad_rgb_marched, const float* weights
   const int64_t threads = M3 > n_last ? M3 : n_last;
   if (!dvgo_fits(threads)) return DVGO_ERANGE;
   march_composite_bwd_kernel<<<dvgo_blocks(threads, DVGO_BLOCK), DVGO_BLOCK, 0, (hipStream_t)stream>>>(
-      grad_rgb_marched, weights, rgb, ray_id, M3, m_dev, grad_weights, grad_rgb, n_last, bg, grad_last);
+      grad_rgb_marched, weights, rgb, ray_id, M3, m_dev, grad_weights, grad_rgb, n_last, bg, grad_last, accumulate);
   DVGO_LAUNCH_CHECK();
   return 0;
 }

@@ -251,7 +251,7 @@ sample_ndc_kernel(const float* __restrict__ rays_o, const float* __restrict__ ra
 // ----------------------------------------------------------------------------------
 extern "C" {
 
-int dvgo_abi_version(void) { return 3; }
+int dvgo_abi_version(void) { return 4; }
 
 int dvgo_infer_t_minmax(const float* rays_o, const float* rays_d, const float* xyz_min,
                         const float* xyz_max, float near, float far, int64_t n_rays,

@@ -876,10 +876,31 @@ shade_wgrad_ring_kernel(const float* __restrict__ G1, const float* __restrict__ 
 // thousand wavefronts stream the 60 MB (one column block alone would leave the chip idle and latency-bound:
 // 124 us -> ~20 us); slices meet in `out` (zeroed by the caller) with one float atomic per element.
 #define SHADE_REDUCE_SLICES 16
+// The sums leave in the COMPACT record the caller hands to the optimizer as views, no repacking launches:
+//   { dW2 [W][W], dW1 [W][d_in], dW3 [3][W], db1 [W], db2 [W], db3 [3] }   (the padded columns / rows of a part are dropped,
+//   the two halves of db3 meet here)
 __global__ void __launch_bounds__(256)
-shade_wgrad_reduce_kernel(const float* __restrict__ part, int n_parts, int n, float* __restrict__ out) {
+shade_wgrad_reduce_kernel(const float* __restrict__ part, int n_parts, int n, int W, int d_in, float* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  int o;                                    // index in the compact record, -1: padding
+  const int nW2 = W * W, nW1 = W * 64, nW3 = 32 * W;
+  if (i < nW2) o = i;
+  else if (i < nW2 + nW1) {
+    const int r = (i - nW2) >> 6, c = (i - nW2) & 63;
+    o = c < d_in ? nW2 + r * d_in + c : -1;
+  } else if (i < nW2 + nW1 + nW3) {
+    const int e = i - nW2 - nW1;
+    o = e < 3 * W ? nW2 + W * d_in + e : -1;
+  } else {
+    const int e = i - nW2 - nW1 - nW3, base = nW2 + W * d_in + 3 * W;
+    if (e < 2 * W) o = base + e;
+    else {
+      const int c = e - 2 * W;
+      o = c < 3 ? base + 2 * W + c : (c >= 8 && c < 11) ? base + 2 * W + c - 8 : -1;
+    }
+  }
+  if (o < 0) return;
   const int per = (n_parts + SHADE_REDUCE_SLICES - 1) / SHADE_REDUCE_SLICES;
   const int p0 = blockIdx.y * per, p1 = min(n_parts, p0 + per);
   float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
@@ -891,7 +912,7 @@ shade_wgrad_reduce_kernel(const float* __restrict__ part, int n_parts, int n, fl
     a3 += part[(int64_t)(p + 3) * n + i];
   }
   for (; p < p1; ++p) a0 += part[(int64_t)p * n + i];
-  if (p1 > p0) atomicAdd(out + i, (a0 + a1) + (a2 + a3));
+  if (p1 > p0) atomicAdd(out + o, (a0 + a1) + (a2 + a3));
 }
 
 extern "C" {
@@ -990,9 +1011,11 @@ int dvgo_shade_wgrad(const float* G1, const float* gz, const uint64_t* masks, co
         G1, gz, (const unsigned int*)masks, W3, H1, H2, feat, C, c_view0, n_view, emb, E, ray_id, M, m_dev, part);
   DVGO_LAUNCH_CHECK();
   const int psize = width * width + width * 64 + 32 * width + 3 * width;
-  if (hipMemsetAsync(total, 0, (size_t)psize * sizeof(float), (hipStream_t)stream) != hipSuccess) return DVGO_EINVAL;
+  const int d_in = n_view + E;
+  const int tsize = width * width + width * d_in + 3 * width + 2 * width + 3;
+  if (hipMemsetAsync(total, 0, (size_t)tsize * sizeof(float), (hipStream_t)stream) != hipSuccess) return DVGO_EINVAL;
   shade_wgrad_reduce_kernel<<<dim3((psize + 255) / 256, SHADE_REDUCE_SLICES), 256, 0, (hipStream_t)stream>>>(part, n_parts, psize,
-                                                                                                       total);
+                                                                                                       width, d_in, total);
   DVGO_LAUNCH_CHECK();
   return 0;
 }

@@ -353,14 +353,20 @@ class _Composite(torch.autograd.Function):
         N = alphainv_last.shape[0]
         rgb = rgb.contiguous()
         weights = weights.contiguous()
+        last = alphainv_last.contiguous()
         out = torch.empty((N, 3), dtype=torch.float32, device=weights.device)
         with L.device_of(weights):
             L.call('dvgo_march_composite', ptr(weights), ptr(rgb), ptr(None), ptr(off3), _i64(N),
-                   ptr(alphainv_last.contiguous()), _flt(float(bg)), ptr(out), ptr(None), stream_of(weights))
+                   ptr(last), _flt(float(bg)), ptr(out), ptr(None), stream_of(weights))
         ctx.save_for_backward(weights, rgb, ray_id)
         ctx.bg = float(bg)
         ctx.N = N
         ctx.m_dev = m_dev
+        # A loss that also consumes `rgb` / `alphainv_last` (run.py:381-385: rgbper, entropy) may leave its gradient of
+        # them in `ctx.extra` instead of returning it to autograd (train._FusedLoss does, after checking these two
+        # pointers): the backward below then adds to it in place -- one gradient per tensor, no summation launches.
+        ctx.rgb_ptr, ctx.last_ptr = rgb.data_ptr(), last.data_ptr()
+        ctx.extra = None
         return out
 
     @staticmethod
@@ -370,11 +376,28 @@ class _Composite(torch.autograd.Function):
         g = g.contiguous()
         M3 = weights.shape[0]
         gw = torch.empty_like(weights) if ctx.needs_input_grad[0] else None
-        grgb = torch.empty_like(rgb) if ctx.needs_input_grad[1] else None
-        glast = torch.empty(ctx.N, dtype=torch.float32, device=g.device) if ctx.needs_input_grad[2] else None
+        extra, ctx.extra = ctx.extra, None
+        if extra is not None:
+            grgb, glast = extra                      # the loss's gradients of rgb / alphainv_last (either may be None)
+            acc = 1
+            if (grgb is None and ctx.needs_input_grad[1]) or (glast is None and ctx.needs_input_grad[2]):
+                # only one of the two was handed over: finish the other the plain way, then add
+                g2 = torch.empty_like(rgb) if grgb is None and ctx.needs_input_grad[1] else None
+                l2 = torch.empty(ctx.N, dtype=torch.float32, device=g.device) if glast is None and ctx.needs_input_grad[2] else None
+                with L.device_of(weights):
+                    L.call('dvgo_march_composite_bwd', ptr(g), ptr(weights), ptr(rgb), ptr(ray_id), _i64(M3), ptr(ctx.m_dev),
+                           _i64(ctx.N), _flt(ctx.bg), ptr(None), ptr(g2), ptr(l2), _int(0), stream_of(weights))
+                with L.device_of(weights):
+                    L.call('dvgo_march_composite_bwd', ptr(g), ptr(weights), ptr(rgb), ptr(ray_id), _i64(M3), ptr(ctx.m_dev),
+                           _i64(ctx.N), _flt(ctx.bg), ptr(gw), ptr(grgb), ptr(glast), _int(1), stream_of(weights))
+                return gw, (grgb if grgb is not None else g2), (glast if glast is not None else l2), None, None, None, None
+        else:
+            grgb = torch.empty_like(rgb) if ctx.needs_input_grad[1] else None
+            glast = torch.empty(ctx.N, dtype=torch.float32, device=g.device) if ctx.needs_input_grad[2] else None
+            acc = 0
         with L.device_of(weights):
             L.call('dvgo_march_composite_bwd', ptr(g), ptr(weights), ptr(rgb), ptr(ray_id), _i64(M3), ptr(ctx.m_dev), _i64(ctx.N),
-                   _flt(ctx.bg), ptr(gw), ptr(grgb), ptr(glast), stream_of(weights))
+                   _flt(ctx.bg), ptr(gw), ptr(grgb), ptr(glast), _int(acc), stream_of(weights))
         return gw, grgb, glast, None, None, None, None
 
 

@@ -154,18 +154,18 @@ class _Shade(torch.autograd.Function):
             n_parts = max(1, min(N_PARTS, (M + 255) // 256))      # >= 8 row tiles per workgroup on small batches
             psize = width * width + width * 64 + 32 * width + 3 * width
             part = torch.empty((n_parts, psize), dtype=torch.float32, device=feat.device)
-            tot = torch.empty(psize, dtype=torch.float32, device=feat.device)
+            tsize = width * width + width * d_in + 5 * width + 3
+            tot = torch.empty(tsize, dtype=torch.float32, device=feat.device)
             with L.device_of(feat):
                 L.call('dvgo_shade_wgrad', ptr(G1), ptr(gz), ptr(masks), ptr(W3.contiguous()), ptr(H1), ptr(H2), ptr(feat), _int(C), ptr(emb),
                        _int(emb.shape[1]), ptr(ray_id), _i64(M), ptr(m_dev), _int(width), _int(1 if diffuse else 0), _int(n_parts),
                        ptr(part), ptr(tot), stream_of(feat))
-            o = 0
+            o = 0                                # the compact record of include/dvgo_hip.h: the gradients are views of it
             gW2 = tot[o:o + width * width].view(width, width); o += width * width
-            gW1 = tot[o:o + width * 64].view(width, 64)[:, :d_in]; o += width * 64
-            gW3 = tot[o:o + 32 * width].view(32, width)[:3]; o += 32 * width
-            gb1, gb2 = tot[o:o + width], tot[o + width:o + 2 * width]
-            gb3 = tot[o + 2 * width:o + 2 * width + 3] + tot[o + 2 * width + 8:o + 2 * width + 11]
-            return gW1.contiguous(), gb1, gW2, gb2, gW3.contiguous(), gb3
+            gW1 = tot[o:o + width * d_in].view(width, d_in); o += width * d_in
+            gW3 = tot[o:o + 3 * width].view(3, width); o += 3 * width
+            gb1, gb2, gb3 = tot[o:o + width], tot[o + width:o + 2 * width], tot[o + 2 * width:o + 2 * width + 3]
+            return gW1, gb1, gW2, gb2, gW3, gb3
 
         gf = g_feat if ctx.needs_input_grad[0] else None
         if defer_wgrad._active is not None:

@@ -104,16 +104,30 @@ class _FusedLoss(torch.autograd.Function):
                    _flt(w_per), ptr(g_marched), ptr(g_last), ptr(g_raw), ptr(loss), stream_of(rgb_marched))
         ctx.save_for_backward(g_marched, g_last, g_raw if g_raw is not None else g_last)
         ctx.has_raw = g_raw is not None
+        # rgb_marched = composite(weights, raw_rgb, alphainv_last): the same two tensors reach the loss directly (rgbper,
+        # entropy) and through the composite.  When that is the producer of `rgb_marched`, this node's gradients of them
+        # are handed to its backward (fused._Composite: `extra`), which adds its own share in place, instead of both being
+        # returned to autograd to be summed by two more launches (one of them over [M, 3]).
+        fn = rgb_marched.grad_fn
+        ctx.partner = None
+        if (fn is not None and getattr(fn, 'rgb_ptr', None) == raw_rgb.data_ptr() and getattr(fn, 'last_ptr', None) ==
+                alphainv_last.data_ptr() and raw_rgb.requires_grad and alphainv_last.requires_grad):
+            ctx.partner = fn
         return loss
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, go):
         g_marched, g_last, g_raw = ctx.saved_tensors
-        if _FusedLoss.unit_grad:         # TrainStep calls loss.backward() itself: d loss / d loss = 1, nothing to scale
-            return (g_marched, g_last, g_raw if ctx.has_raw else None, None, None, None, None, None, None, None, None)
-        return (g_marched * go, g_last * go, (g_raw * go) if ctx.has_raw else None, None, None, None, None, None, None,
-                None, None)
+        unit = _FusedLoss.unit_grad      # TrainStep calls loss.backward() itself: d loss / d loss = 1, nothing to scale
+        gm = g_marched if unit else g_marched * go
+        gl = g_last if unit else g_last * go
+        gr = (g_raw if unit else g_raw * go) if ctx.has_raw else None
+        if ctx.partner is not None:
+            ctx.partner.extra = (gr, gl)
+            ctx.partner = None
+            return (gm, None, None, None, None, None, None, None, None, None, None)
+        return (gm, gl, gr, None, None, None, None, None, None, None, None)
 
 
 def fused_render_loss(render_result, target, n_rays_global, cfg_train):

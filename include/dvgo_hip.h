@@ -241,11 +241,12 @@ int dvgo_march_composite(const float* weights, const float* rgb /* [M3,3] */,
 /* Backward of the composite w.r.t. weights and rgb (either output may be NULL):
  *   grad_weights[i] = sum_c g[r,c]*rgb[i,c] ; grad_rgb[i,c] = g[r,c]*weights[i], r = ray_id[i].
  *   grad_last (NULL or [n_rays]) = bg * sum_c g[r,c], the gradient w.r.t. alphainv_last (lib/dvgo.py:559),
- *   written by the same launch. */
+ *   written by the same launch.  accumulate != 0: grad_rgb and grad_last already hold the gradient of the same two
+ *   tensors through another consumer (the loss's rgbper and entropy terms, run.py:381-385) and are added to. */
 int dvgo_march_composite_bwd(const float* grad_rgb_marched /* [N,3] */, const float* weights,
                              const float* rgb, const int64_t* ray_id, int64_t M3, const int64_t* m_dev, int64_t n_rays,
                              float bg, float* grad_weights /* [M3] */, float* grad_rgb /* [M3,3] */,
-                             float* grad_last, void* stream);
+                             float* grad_last, int accumulate, void* stream);
 
 /* dvgo_march_feat_bwd: scatter grad_feat [M3,C] into grad_k0 (float atomics, de-duplicated per wavefront in LDS;
  *   element strides sC,sX,sY,sZ of the destination).
@@ -395,7 +396,8 @@ int dvgo_shade_bwd(const float* g_rgb, const float* rgb, const uint64_t* masks, 
  * with both operands read row-major straight from memory.  Every one of the n_parts workgroups writes its
  * partial sums to part[p] = { dW2 [width][width], dW1 [width][64], dW3 [32][width] (rows 0..2 valid),
  * db1 [width], db2 [width], db3 [width] (db3[c] = entry c + entry 8+c, c < 3) } floats (scratch), and a second launch sums them over p
- * into `total` (same record layout, once). */
+ * into `total`, the compact record { dW2 [width][width], dW1 [width][d_in], dW3 [3][width], db1 [width], db2 [width], db3 [3] }
+ * (d_in = (C - 3 * diffuse) + E; width^2 + width * d_in + 5 * width + 3 floats): views of it are the gradients. */
 int dvgo_shade_wgrad(const float* G1, const float* gz, const uint64_t* masks, const float* W3,
                      const float* H1, const float* H2, const float* feat, int C, const float* emb, int E, const int64_t* ray_id, int64_t M,
                      const int64_t* m_dev, int width, int diffuse, int n_parts, float* part, float* total, void* stream);

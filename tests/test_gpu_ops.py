@@ -382,6 +382,36 @@ def _shade_vs_torch(M, diffuse, width, C, E):
             assert np.linalg.norm(a - b) <= 2e-2 * np.linalg.norm(b)
 
 
+@pytest.mark.parametrize('width,C,E,diffuse', [(64, 9, 3, True), (128, 12, 27, False), (128, 12, 27, True)])
+def test_shade_is_bitwise_repeatable(width, C, E, diffuse):
+    """The colour head has no atomics on its value / data-gradient path: the same inputs must give the same bits, run
+    after run, with several tiles per wavefront.  (Guards the operand-register hazard described in csrc/shade_x3.hip
+    x3_split8: before the fix the 64-wide head differed in ~100 rows of 400 000 on EVERY repeat, by 1e-4 relative.)"""
+    from directvoxgo_amd.dvgo import make_rgbnet
+    from directvoxgo_amd.shade import shade
+    torch.manual_seed(1)
+    M = 400000
+    d_in = (C - 3 if diffuse else C) + E
+    net = make_rgbnet(d_in, width, 3).cuda()
+    feat = torch.randn(M, C, device='cuda', requires_grad=True)
+    emb = torch.randn(4096, E, device='cuda')
+    ray_id = torch.sort(torch.randint(4096, (M,), device='cuda'))[0]
+    go = torch.randn(M, 3, device='cuda')
+    ref = None
+    for it in range(12):
+        junk = torch.full((1 << 22,), float('nan'), device='cuda')      # different allocator state, poisoned
+        del junk
+        rgb = shade(net, feat, emb, ray_id, diffuse)
+        g_feat = torch.autograd.grad(rgb, feat, go)[0]
+        cur = (rgb.detach().clone(), g_feat.clone())
+        if ref is None:
+            ref = cur
+        else:
+            assert torch.equal(cur[0], ref[0]), f'rgb differs on repeat {it}'
+            bad = (cur[1] != ref[1]).any(1).sum()
+            assert int(bad) == 0, f'{int(bad)} rows of the feature gradient differ on repeat {it}'
+
+
 def test_shade_falls_back_for_other_heads():
     from directvoxgo_amd.dvgo import make_rgbnet
     from directvoxgo_amd.shade import shade
