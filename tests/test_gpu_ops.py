@@ -445,6 +445,38 @@ def test_fused_loss_matches_reference_formula():
                 np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=1e-5, atol=1e-10)
 
 
+def test_loss_gradients_handed_to_the_composite_backward_equal_autograd_sums():
+    """rgb_marched = composite(weights, raw_rgb, alphainv_last) and the loss reads raw_rgb / alphainv_last directly too
+    (rgbper, entropy).  The fused loss hands its gradients of those two to the composite's backward, which adds its share in
+    place (dvgo_march_composite_bwd, accumulate) -- same result as letting autograd sum the two contributions."""
+    from directvoxgo_amd.fused import composite
+    from directvoxgo_amd.train import FINE_TRAIN, fused_render_loss, render_loss
+    torch.manual_seed(3)
+    N, M = 513, 30011
+    rid = torch.sort(torch.randint(N, (M,), device='cuda'))[0]
+    off3 = torch.zeros(N + 1, dtype=torch.int64, device='cuda')
+    off3[1:] = torch.cumsum(torch.bincount(rid, minlength=N), 0)
+    tgt = torch.rand(N, 3, device='cuda')
+    for cfg in (dict(FINE_TRAIN), dict(FINE_TRAIN, weight_rgbper=0.0), dict(FINE_TRAIN, weight_entropy_last=0.0)):
+        grads = []
+        for fused in (True, False):
+            w = torch.rand(M, device='cuda').mul_(0.05).requires_grad_()
+            rgb = torch.rand(M, 3, device='cuda').requires_grad_()
+            last = torch.rand(N, device='cuda').requires_grad_()
+            torch.manual_seed(4)                       # (same leaves both times)
+            with torch.no_grad():
+                w.copy_(torch.rand(M, device='cuda') * 0.05); rgb.copy_(torch.rand(M, 3, device='cuda')); last.copy_(torch.rand(N, device='cuda'))
+            marched = composite(w, rgb, last, rid, off3, 1.0)
+            res = {'rgb_marched': marched, 'alphainv_last': last, 'raw_rgb': rgb, 'weights': w, 'ray_id': rid}
+            loss = (fused_render_loss if fused else render_loss)(res, tgt, N, cfg)
+            if fused:                                  # the hand-over is armed exactly when the loss reads these tensors
+                assert (marched.grad_fn.rgb_ptr, marched.grad_fn.last_ptr) == (rgb.data_ptr(), last.data_ptr())
+            grads.append((float(loss),) + torch.autograd.grad(loss, [w, rgb, last]))
+        np.testing.assert_allclose(grads[0][0], grads[1][0], rtol=2e-5)
+        for a, b in zip(grads[0][1:], grads[1][1:]):
+            np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-5, atol=1e-9)
+
+
 def test_viewdir_embed_matches_torch_expression():
     from directvoxgo_amd.shade import viewdir_embed
     v = torch.nn.functional.normalize(torch.randn(1000, 3, device='cuda'), dim=-1)
