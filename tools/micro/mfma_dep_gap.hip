@@ -13,10 +13,10 @@ using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
 
 template <int K, bool F32>
-__global__ void __launch_bounds__(256) k(const u32x4* __restrict__ a, const u32x4* __restrict__ b, int* __restrict__ bad, int iters) {
+__global__ void __launch_bounds__(512) k(const u32x4* __restrict__ a, const u32x4* __restrict__ b, int* __restrict__ bad, int iters) {
   __shared__ char pad[100 * 1024];                     // one workgroup per CU
   if (iters < 0) pad[threadIdx.x] = 0;
-  const u32x4 A = a[threadIdx.x & 63], B = b[threadIdx.x & 63];
+  const u32x4 A = a[threadIdx.x & 63], B = b[threadIdx.x & 63];   // (the f32 variant's check is not exact: ignore F32 = true)
   int wrong = 0;
   float d0 = 1.0f, d1 = 2.0f, d2 = 3.0f, d3 = 4.0f;
   for (int it = 0; it < iters; ++it) {
@@ -52,15 +52,16 @@ __global__ void __launch_bounds__(256) k(const u32x4* __restrict__ a, const u32x
   if (wrong || d0 + d1 + d2 + d3 == 12345.f) atomicAdd(bad, wrong);
 }
 
+static int THREADS = 256;          // 256: one wave per SIMD; 512: two (the second competes for the matrix pipe)
 template <int K, bool F32>
 void run(const u32x4* a, const u32x4* b, int* bad) {
   hipMemset(bad, 0, 4);
-  k<K, F32><<<256, 256>>>(a, b, bad, 2000);
+  k<K, F32><<<256, THREADS>>>(a, b, bad, 2000);
   hipDeviceSynchronize();
   int h = 0;
   hipMemcpy(&h, bad, 4, hipMemcpyDeviceToHost);
-  printf("%s  K = %2d VALU between dependent MFMAs: %9d wrong elements of %lld\n", F32 ? "f32 32x32x2  " : "bf16 32x32x16", K, h,
-         256LL * 256 * 2000 * 16);
+  printf("%d waves/SIMD %s  K = %2d VALU between dependent MFMAs: %9d wrong elements of %lld\n", THREADS / 256, F32 ? "f32 32x32x2  " : "bf16 32x32x16", K, h,
+         256LL * THREADS * 2000 * 16);
 }
 
 int main() {
@@ -72,8 +73,10 @@ int main() {
   hipMalloc(&a, 64 * 16); hipMalloc(&b, 64 * 16); hipMalloc(&bad, 4);
   hipMemcpy(a, ha.data(), 64 * 16, hipMemcpyHostToDevice);
   hipMemcpy(b, hb.data(), 64 * 16, hipMemcpyHostToDevice);
-  run<0, false>(a, b, bad); run<1, false>(a, b, bad); run<2, false>(a, b, bad); run<3, false>(a, b, bad); run<4, false>(a, b, bad);
-  run<6, false>(a, b, bad); run<8, false>(a, b, bad); run<10, false>(a, b, bad); run<12, false>(a, b, bad); run<16, false>(a, b, bad);
-  run<0, true>(a, b, bad); run<2, true>(a, b, bad); run<4, true>(a, b, bad); run<8, true>(a, b, bad); run<16, true>(a, b, bad);
+  for (int th : {256, 512}) {
+    THREADS = th;
+    run<0, false>(a, b, bad); run<1, false>(a, b, bad); run<2, false>(a, b, bad); run<3, false>(a, b, bad); run<4, false>(a, b, bad);
+    run<6, false>(a, b, bad); run<8, false>(a, b, bad); run<10, false>(a, b, bad); run<12, false>(a, b, bad); run<16, false>(a, b, bad);
+  }
   return 0;
 }
