@@ -1,8 +1,12 @@
+"""Runs the colour head with every register and the LDS of every CU filled with NaNs in front of each of our launches
+(needs tools/debug_pollute.hip built into the library: see its header).  No NaN may come out and results may not move."""
 import sys, os, ctypes, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from directvoxgo_amd import _lib as L
 from directvoxgo_amd.dvgo import make_rgbnet
 from directvoxgo_amd.shade import shade
+if not hasattr(L.lib(), 'dvgo_debug_pollute_registers'):
+    sys.exit('libdvgo_hip.so was built without tools/debug_pollute.hip (see the header of that file)')
 _orig = L.call
 POLLUTE = [False]
 def call(name, *args):
