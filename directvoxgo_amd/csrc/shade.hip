@@ -626,8 +626,10 @@ shade_wgrad_ring_kernel(const float* __restrict__ G1, const float* __restrict__ 
                         const float* __restrict__ W3, const float* __restrict__ H1, const float* __restrict__ H2,
                         const float* __restrict__ feat, int C, int c_view0, int n_view, const float* __restrict__ emb, int E,
                         const int64_t* __restrict__ ray_id, int64_t M_cap, const int64_t* __restrict__ m_dev,
-                        float* __restrict__ part /* [gridDim][WIDTH*WIDTH + WIDTH*64 + 32*WIDTH + 3*WIDTH] */) {
-#if defined(__HIP_DEVICE_COMPILE__)   // buffer descriptors are device-only types: the host pass needs the launch stub only
+                        float* __restrict__ part /* [gridDim][WIDTH*WIDTH + WIDTH*64 + 32*WIDTH + 3*WIDTH] */,
+                        float* __restrict__ total, int total_size /* zeroed here for the reduce kernel's atomics */) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total_size; i += gridDim.x * blockDim.x) total[i] = 0.0f;   // buffer descriptors are device-only types: the host pass needs the launch stub only
   // (everything the DMA descriptors, scalar offsets and LDS targets are built from must be PROVABLY wave-uniform, or the
   // compiler wraps each DMA in a readfirstlane loop: the row count comes from memory, the wave index from threadIdx)
   int64_t M;
@@ -990,6 +992,7 @@ int dvgo_shade_wgrad(const float* G1, const float* gz, const uint64_t* masks, co
   const int c_view0 = diffuse ? 3 : 0;
   const int n_view = C - c_view0;
   if ((width != 128 && width != 64) || n_view < 0 || n_view + E > 40) return DVGO_ERANGE;
+  bool ring = false;                        // (the pipelined kernel zeroes `total` itself: one launch less)
   if (g_shade_variant & 4) {
     if (n_parts > 256) n_parts = 256;       // one 8-wave workgroup per CU (141 KB of LDS)
     const int rc = dvgo_shade_wgrad_x3(G1, gz, masks, W3, H1, H2, feat, C, emb, E, ray_id, M, m_dev, width, diffuse, n_parts, part, stream);
@@ -997,12 +1000,14 @@ int dvgo_shade_wgrad(const float* G1, const float* gz, const uint64_t* masks, co
   } else if (!(g_shade_variant & 8) && n_view <= 16 && E <= 32 && (n_view + E <= 32 || (n_view % 4 == 0 && n_view >= 8)) &&
              M * width * 4 < ((int64_t)1 << 31) && M * C * 4 < ((int64_t)1 << 31)) {
     if (n_parts > 512) n_parts = 512;       // two workgroups per CU (55 KB of LDS each)
+    ring = true;
+    const int tsz = width * width + width * (n_view + E) + 5 * width + 3;
     if (width == 128)
       shade_wgrad_ring_kernel<128><<<n_parts, 256, 0, (hipStream_t)stream>>>(
-          G1, gz, (const unsigned int*)masks, W3, H1, H2, feat, C, c_view0, n_view, emb, E, ray_id, M, m_dev, part);
+          G1, gz, (const unsigned int*)masks, W3, H1, H2, feat, C, c_view0, n_view, emb, E, ray_id, M, m_dev, part, total, tsz);
     else
       shade_wgrad_ring_kernel<64><<<n_parts, 128, 0, (hipStream_t)stream>>>(
-          G1, gz, (const unsigned int*)masks, W3, H1, H2, feat, C, c_view0, n_view, emb, E, ray_id, M, m_dev, part);
+          G1, gz, (const unsigned int*)masks, W3, H1, H2, feat, C, c_view0, n_view, emb, E, ray_id, M, m_dev, part, total, tsz);
   } else if (width == 128)
     shade_wgrad_kernel<128><<<n_parts, 256, 0, (hipStream_t)stream>>>(
         G1, gz, (const unsigned int*)masks, W3, H1, H2, feat, C, c_view0, n_view, emb, E, ray_id, M, m_dev, part);
@@ -1013,7 +1018,7 @@ int dvgo_shade_wgrad(const float* G1, const float* gz, const uint64_t* masks, co
   const int psize = width * width + width * 64 + 32 * width + 3 * width;
   const int d_in = n_view + E;
   const int tsize = width * width + width * d_in + 3 * width + 2 * width + 3;
-  if (hipMemsetAsync(total, 0, (size_t)tsize * sizeof(float), (hipStream_t)stream) != hipSuccess) return DVGO_EINVAL;
+  if (!ring && hipMemsetAsync(total, 0, (size_t)tsize * sizeof(float), (hipStream_t)stream) != hipSuccess) return DVGO_EINVAL;
   shade_wgrad_reduce_kernel<<<dim3((psize + 255) / 256, SHADE_REDUCE_SLICES), 256, 0, (hipStream_t)stream>>>(part, n_parts, psize,
                                                                                                        width, d_in, total);
   DVGO_LAUNCH_CHECK();
