@@ -43,9 +43,12 @@ HOT_KERNELS = ['dvgo_sample_pts_prepare', 'dvgo_march_density', 'dvgo_exclusive_
                'dvgo_brick_scan', 'dvgo_march_scans', 'dvgo_brick_accumulate']
 
 
-def algorithmic_bytes(name, N, M_d, M2, M_k, C, n_grid):
+def algorithmic_bytes(name, N, M_d, M2, M_k, C, n_grid, adam_in_brick=True):
     """SURVEY.md section 8d, per launch.  M_d: samples whose density is interpolated, M_k: samples whose
-    features are interpolated.  Scratch/ids that only exist because of how the work is split are not counted."""
+    features are interpolated.  Scratch/ids that only exist because of how the work is split are not counted.
+    `adam_in_brick`: the brick scatter applied the masked Adam update from its LDS tile (one GPU, no TV); otherwise
+    (data parallel, TV steps) the launch writes the dense gradients and the optimizer's bytes belong to dvgo_adam_upd."""
+    n_vox = n_grid // (C + 1)
     return {
         'dvgo_sample_pts_prepare': N * (24 + 4 + 4 + 8 + 24),
         'dvgo_march_density': M_d * (8 * 4 + 1 + 4 + 4) + N * 40,          # corner gathers, mask byte, alpha, w
@@ -64,7 +67,8 @@ def algorithmic_bytes(name, N, M_d, M2, M_k, C, n_grid):
         # owner-computes scatter with the Adam update applied from the LDS tile: the scatter's algorithmic bytes
         # (8 corner rows of C + 1 floats per sample + the sample's gradient row) + Adam's 6 x (C + 1) x 4 B
         # (p, m, v read and written) per voxel
-        'dvgo_brick_accumulate': M_k * (8 * (C + 1) * 4 + (C + 1) * 4) + (n_grid // (C + 1)) * 6 * (C + 1) * 4,
+        # -- or, without the update, the dense gradient write of every voxel ((C + 1) x 4 B)
+        'dvgo_brick_accumulate': M_k * (8 * (C + 1) * 4 + (C + 1) * 4) + n_vox * (C + 1) * 4 * (6 if adam_in_brick else 1),
         # colour head (row N3): MFMA-bound, bytes listed for completeness (features / activations in and out)
         'dvgo_shade_fwd': M_k * (C * 4 + 8 + 12 + 2 * 512),
         'dvgo_shade_bwd': M_k * (24 + 32 + 512 + C * 4),
@@ -343,6 +347,48 @@ def cpu_baseline(sc_cpu, m, rk, n_rays_total, sample_rays):
     return out
 
 
+def launch_ranks(n, argv, python=None):
+    """Start `n` ranks of this script under torch.distributed.run (one per GPU, rendezvous on 127.0.0.1) as a child job;
+    relay its stdout line by line; return its exit status.  The caller has not touched the GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [python or sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    print('bench.py: launching ' + ' '.join(cmd), file=sys.stderr, flush=True)
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return proc.wait()
+
+
+def dry_run(args, world, rank):
+    """No GPU: join the group, agree on a step time the way the timed region does (barrier, MAX over ranks), print the line."""
+    backend = args.backend
+    if world > 1:
+        dist.init_process_group(backend)
+        dist.barrier()
+        t = torch.tensor([1.0 + rank], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        seen = dist.get_world_size()
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        dt, seen = 1.0, 1
+    if rank == 0:
+        print(json.dumps({'metric': 'train rays/sec (8192-ray batch, 160^3 grid)', 'value': None, 'unit': 'rays/s', 'n_gpus': world,
+                          'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': None, 'higher_is_better': True,
+                          'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic', 'dry_run': True,
+                          'backend': backend, 'rccl_ranks_seen': seen, 'max_over_ranks_check': dt}))
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -363,10 +409,24 @@ def main():
                     help='timed region without the second-stream overlap of the colour-head weight gradients: every launch '
                          'of a kernel then runs alone, so rocprofv3 --stats averages agree with the HIP-event averages')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend for N > 1 ('nccl' = RCCL on ROCm)")
+    ap.add_argument('--dry-run', action='store_true',
+                    help='launcher / rendezvous check without touching a GPU: every rank joins the process group (use --backend '
+                         'gloo on a CPU box), the ranks agree on a dummy step time, rank 0 prints the JSON line')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` (the driver's single-GPU command shape with N > 1): this process must not touch the GPU
+        # (a process that has initialised HIP may not exec or share its device with the ranks); it starts the ranks as a
+        # CHILD job, relays their output (rank 0's JSON line) and exits with the job's status
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with '
+                         f'`python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} ... bench.py --gpus {args.gpus}` '
+                         f'or plain `python bench.py --gpus {args.gpus}`')
+    if args.dry_run:
+        return dry_run(args, world, rank)
     if args.scaling == 'strong':
         assert args.rays % world == 0
         args.rays //= world              # from here on: rays per GPU
@@ -382,7 +442,6 @@ def main():
             dist.init_process_group(args.backend)
     else:
         torch.cuda.set_device(0)
-    assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
     device = torch.device('cuda', dev_index)
 
     from directvoxgo_amd.train import FINE_TRAIN, TrainStep
@@ -397,11 +456,13 @@ def main():
         captured = bool(graph) and step.capture(*pool[0], global_step=5000)
         dt, prof = timed_region(step, pool, steps, warmup, world, profile and not captured)
         run.captured = captured
+        run.adam_in_brick = bool(getattr(step, 'last_fused_adam', False))     # did the scatter launch carry the Adam update?
         end_counts = count_samples(m, pool[0], rk)          # the optimizer moves the scene: how far did the workload drift?
         return sc, m, rk, dt, prof, (M0, M_d, M_k), end_counts
 
     sc, m, rk, dt, prof, (M0, M_d, M_k), end_counts = run(args.workload, args.steps, args.warmup, True, graph=args.graph)
     primary_captured = bool(getattr(run, 'captured', False))
+    adam_in_brick = bool(getattr(run, 'adam_in_brick', False))
     n_total = args.rays * world
     value = n_total * args.steps / dt
 
@@ -412,9 +473,10 @@ def main():
         if cnt == 0:
             continue
         per_ms = ms / cnt
-        ab = algorithmic_bytes(name, args.rays, M_d, M_k if args.workload == 'roofline' else M_k, M_k, C, n_grid)
+        ab = algorithmic_bytes(name, args.rays, M_d, M_k if args.workload == 'roofline' else M_k, M_k, C, n_grid, adam_in_brick)
         if name == 'dvgo_adam_upd':
-            ab = 28 * n_grid / max(cnt / args.steps, 1)          # average per call over the param tensors
+            # average per call over the param tensors; data parallel: each rank sweeps the 1/world slab it owns
+            ab = 28 * (n_grid / world) / max(cnt / args.steps, 1)
         if name == 'dvgo_grid_grad_split':
             ab = (64 + 52) * m.density.numel()
         if name == 'dvgo_adam_rows':
@@ -452,6 +514,8 @@ def main():
         'roofline': roofline, 'north_star_kernels': ns, 'kernels': kernels,
         'kernel_timing': 'HIP events around each launch, second pass of the same K steps with all kernels on one stream',
         'hip_graph': primary_captured,
+        'backend': (dist.get_backend() if world > 1 else None), 'rccl_ranks_seen': (dist.get_world_size() if world > 1 else 1),
+        'adam_fused_into_scatter': adam_in_brick,
     }
 
     from directvoxgo_amd import _lib as L_

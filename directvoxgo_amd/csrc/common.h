@@ -140,17 +140,16 @@ __device__ __forceinline__ double dvgo_readlane_d(double v, int lane) {
 #define DVGO_BRICK (1 << DVGO_BRICK_LOG)
 
 // distinct brick coordinates of the in-range voxels {i0, i0+1} on one axis; returns how many (0..2)
+// (selects only: with branches and by-reference outputs hipcc turned the six brick coordinates of a sample into a
+// dynamically indexed private array -- 28 B of scratch per lane in both march kernels)
 __device__ __forceinline__ int dvgo_brick_axis(int i0, int n, int& b0, int& b1) {
-  int c = 0;
-  b0 = b1 = 0;
-  if (i0 >= 0 && i0 < n) { b0 = i0 >> DVGO_BRICK_LOG; c = 1; }
   const int i1 = i0 + 1;
-  if (i1 >= 0 && i1 < n) {
-    const int v = i1 >> DVGO_BRICK_LOG;
-    if (c == 0) { b0 = v; c = 1; }
-    else if (v != b0) { b1 = v; c = 2; }
-  }
-  return c;
+  const bool in0 = (i0 >= 0) & (i0 < n), in1 = (i1 >= 0) & (i1 < n);
+  const int v0 = i0 >> DVGO_BRICK_LOG, v1 = i1 >> DVGO_BRICK_LOG;
+  const bool two = in0 & in1 & (v1 != v0);
+  b0 = in0 ? v0 : (in1 ? v1 : 0);
+  b1 = two ? v1 : 0;
+  return two ? 2 : ((in0 | in1) ? 1 : 0);
 }
 
 __device__ __forceinline__ unsigned long long dvgo_lanemask_le(int lane) { return ~0ull >> (63 - lane); }

@@ -439,6 +439,7 @@ class TrainStep:
                and isinstance(density, nn.Parameter) and isinstance(k0, nn.Parameter) and density.is_cuda)
         fuse_adam = own and self.optimizer.can_fuse_grid_step(density, k0)
         use_rows = fuse_adam or (own and self.optimizer.can_step_grid_rows(density, k0))
+        self.last_fused_adam = bool(fuse_adam)       # (bench.py: which bytes the scatter launch is credited with)
         opt = self.optimizer
         rows = (grid_rows_capture(density, k0, adam=(lambda: opt.grid_step_args(density, k0)) if fuse_adam else None)
                 if use_rows else contextlib.nullcontext())
