@@ -84,6 +84,57 @@ __device__ __forceinline__ bool dvgo_tri_inb(const TriSetup& t, int n, int X, in
   return (i >= 0) & (i < X) & (j >= 0) & (j < Y) & (k >= 0) & (k < Z);
 }
 
+// --------------------------------------------------------------------------------------
+// Single-channel trilinear value with every corner load in flight at once.  The straightforward form -- `if (in
+// bounds) d = fmaf(grid[off], w, d)` per corner -- compiles to eight dependent round trips (load, s_waitcnt
+// vmcnt(0), fma, next corner); here the loads are unconditional (out-of-range corners read a clamped, valid
+// address and are dropped by a select), the two z-neighbours of a corner pair arrive as ONE 8-byte load (Z is the
+// innermost axis: they are adjacent dwords; 4-byte aligned, which global loads allow), and the fma chain runs
+// afterwards in the reference's corner order, skipping out-of-range corners exactly as before: same bits.
+// Needs Z >= 2.
+// --------------------------------------------------------------------------------------
+struct __attribute__((packed, aligned(4))) dvgo_f2u { float x, y; };
+
+__device__ __forceinline__ float dvgo_tri_value_c1(const float* __restrict__ grid, const TriSetup& t, int X, int Y, int Z) {
+  const int i1 = t.i0 + 1, j1 = t.j0 + 1, k1 = t.k0 + 1;
+  const bool x0 = (t.i0 >= 0) & (t.i0 < X), x1 = (i1 >= 0) & (i1 < X);
+  const bool y0 = (t.j0 >= 0) & (t.j0 < Y), y1 = (j1 >= 0) & (j1 < Y);
+  const bool z0 = (t.k0 >= 0) & (t.k0 < Z), z1 = (k1 >= 0) & (k1 < Z);
+  const int ia = min(max(t.i0, 0), X - 1), ib = min(max(i1, 0), X - 1);
+  const int ja = min(max(t.j0, 0), Y - 1), jb = min(max(j1, 0), Y - 1);
+  const int kb = min(max(t.k0, 0), Z - 2);
+  const dvgo_f2u q00 = *reinterpret_cast<const dvgo_f2u*>(grid + ((int64_t)(ia * Y + ja) * Z + kb));
+  const dvgo_f2u q01 = *reinterpret_cast<const dvgo_f2u*>(grid + ((int64_t)(ia * Y + jb) * Z + kb));
+  const dvgo_f2u q10 = *reinterpret_cast<const dvgo_f2u*>(grid + ((int64_t)(ib * Y + ja) * Z + kb));
+  const dvgo_f2u q11 = *reinterpret_cast<const dvgo_f2u*>(grid + ((int64_t)(ib * Y + jb) * Z + kb));
+  // kb == k0 except at the faces: k0 == -1 -> kb = 0 (voxel k1 = 0 is .x), k0 == Z-1 -> kb = Z-2 (voxel k0 is .y)
+  const bool lo = t.k0 < kb, hi = t.k0 > kb;
+#define DVGO_ZSEL(q, v0, v1) const float v0 = hi ? q.y : q.x, v1 = lo ? q.x : q.y
+  DVGO_ZSEL(q00, v000, v001); DVGO_ZSEL(q01, v010, v011); DVGO_ZSEL(q10, v100, v101); DVGO_ZSEL(q11, v110, v111);
+#undef DVGO_ZSEL
+  float d = 0.f;
+  d = (x0 & y0 & z0) ? fmaf(v000, (t.wz0 * t.wy0) * t.wx0, d) : d;
+  d = (x0 & y0 & z1) ? fmaf(v001, (t.wz1 * t.wy0) * t.wx0, d) : d;
+  d = (x0 & y1 & z0) ? fmaf(v010, (t.wz0 * t.wy1) * t.wx0, d) : d;
+  d = (x0 & y1 & z1) ? fmaf(v011, (t.wz1 * t.wy1) * t.wx0, d) : d;
+  d = (x1 & y0 & z0) ? fmaf(v100, (t.wz0 * t.wy0) * t.wx1, d) : d;
+  d = (x1 & y0 & z1) ? fmaf(v101, (t.wz1 * t.wy0) * t.wx1, d) : d;
+  d = (x1 & y1 & z0) ? fmaf(v110, (t.wz0 * t.wy1) * t.wx1, d) : d;
+  d = (x1 & y1 & z1) ? fmaf(v111, (t.wz1 * t.wy1) * t.wx1, d) : d;
+  return d;
+}
+
+// x^y for x >= 1 (or +inf) and y < 0: the power of K9 / K10 (render_utils_kernel.cu:367,404: `pow(1 + exp_d, -interval)`),
+// as exp2(y * log2 x) on the hardware's v_log_f32 / v_exp_f32.  The C library's powf is ~200 VALU instructions of
+// special-case handling (negative bases, integer exponents, denormals) that this argument range never needs -- a
+// seventh of the instructions of the VALU-bound march_density kernel.  x = 1 -> 1, x = +inf -> 0, as pow.  Every kernel
+// that evaluates the activation calls this one function, so the fused and the op-by-op paths agree bit for bit; against
+// the CPU oracle (glibc powf) alpha stays inside the activation's stated tolerance (rtol 1e-5 / atol 1e-6: the result
+// p is within a few ulp, and alpha = 1 - p inherits p's ABSOLUTE error, <= ~2e-7).
+__device__ __forceinline__ float dvgo_pow_neg(float x, float y) {
+  return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x));
+}
+
 // Sample position on a ray: K6 (render_utils_kernel.cu:178-181): dist = stepdist * step,
 // p = start + dir * dist (contracted)
 __device__ __forceinline__ void dvgo_sample_pos(const float* __restrict__ start,
@@ -124,6 +175,19 @@ __device__ __forceinline__ int64_t dvgo_upper_bound(const int64_t* __restrict__ 
 
 __device__ __forceinline__ float dvgo_readlane_f(float v, int lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+// v with lane `lane` (wave-uniform) replaced by the wave-uniform value s: one v_writelane_b32 (this hipcc has no
+// __builtin_amdgcn_writelane; the declaration below binds the LLVM intrinsic by its name)
+extern "C" __device__ int dvgo_llvm_writelane_i32(int, int, int) __asm("llvm.amdgcn.writelane.i32");
+__device__ __forceinline__ float dvgo_writelane_f(float s, int lane, float v) {
+  return __int_as_float(dvgo_llvm_writelane_i32(__float_as_int(s), lane, __float_as_int(v)));
+}
+// v_readlane_b32 the optimiser cannot see through: in the transmittance walk it would otherwise read the two halves of
+// the double product and narrow on the scalar side (two more vector instructions per step)
+__device__ __forceinline__ float dvgo_readlane_opaque_f(float v, int lane) {
+  int o;
+  asm("v_readlane_b32 %0, %1, %2" : "=s"(o) : "v"(v), "s"(lane));
+  return __int_as_float(o);
 }
 __device__ __forceinline__ double dvgo_readlane_d(double v, int lane) {
   const long long b = __double_as_longlong(v);

@@ -57,7 +57,7 @@ __device__ __forceinline__ int64_t rec_base(const int64_t* __restrict__ cum, con
 }
 
 // run-time selectable kernel variants (A/B measurements in one process; defaults = fastest measured)
-static int g_tuning[DVGO_TUNE_COUNT] = {1, 1, 0, 0, 0, 0, 0, 0};
+static int g_tuning[DVGO_TUNE_COUNT] = {1, 1, 1, 1, 0, 0, 0, 0};
 
 struct MarchParams {
   float mnx, mny, mnz, mxx, mxy, mxz;
@@ -145,6 +145,59 @@ __device__ __forceinline__ void brick_emit(bool act, int i0, int j0, int k0, int
   }
 }
 
+// ----------------------------------------------------------------------------------
+// The transmittance walk of one 64-step chunk (K12, render_utils_kernel.cu:448-454), hand-scheduled: hipcc's version of
+// the same loop spends 8 vector + 11 scalar instructions per kept sample -- the carry bounces between a VGPR and an SGPR,
+// the set of samples still to do is updated with 64-bit adds -- and that loop is more than a third of the instructions
+// of the VALU-bound march_density kernel.  Here a step is 5 vector + 6 scalar instructions and the carry never leaves
+// the scalar file:
+//   m0 <- next kept lane j; clear it;  T_before[j] <- T (v_writelane);  T <- (float)((double)T * f[j])  -- the widening,
+//   the double multiply and the narrowing run on all lanes, v_readlane picks lane j's result;  stop when T < 1e-3.
+// `todo`: kept lanes (wave-uniform), `f`: per-lane double factor 1 - alpha + 1e-10.  Returns the lane that stopped the ray
+// or -1.  Must be called with all 64 lanes active.  Same operations on the same values as the loop it replaces.
+// Hazards hipcc would have padded (GCNHazardRecognizer, gfx940+) and an asm statement must pad itself: VALU writes a VGPR ->
+// v_readlane of it: 1 wait state (the s_nop); VALU (v_readlane) writes an SGPR -> VALU reads it: 2 wait states (six scalar
+// instructions lie between the v_readlane and the next step's v_cvt / v_writelane).
+// ----------------------------------------------------------------------------------
+__device__ __forceinline__ int chain_walk(unsigned long long todo, double f, float& Tc, float& T_before) {
+  int tc = __builtin_amdgcn_readfirstlane(__float_as_int(Tc));
+  int tb = __float_as_int(T_before);
+  int sl = -1;
+  double d;
+  int t;
+  asm volatile(
+      "s_cmp_eq_u64 %[todo], 0\n\t"
+      "s_cbranch_scc1 2f\n"
+      "1:\n\t"
+      "s_ff1_i32_b64 m0, %[todo]\n\t"
+      "s_bitset0_b64 %[todo], m0\n\t"
+      "v_cvt_f64_f32 %[d], %[tc]\n\t"
+      "v_writelane_b32 %[tb], %[tc], m0\n\t"
+      "v_mul_f64 %[d], %[d], %[f]\n\t"
+      "v_cvt_f32_f64 %[t], %[d]\n\t"
+      "s_nop 0\n\t"                              // gfx940+: a VGPR written by the VALU needs 1 wait state before v_readlane reads it
+      "v_readlane_b32 %[tc], %[t], m0\n\t"
+      "s_cmp_lt_u32 %[tc], 0x3a83126f\n\t"      // (double)T < 1e-3 <=> T < 1e-3f; T >= 0: unsigned compare of the bits
+      "s_cbranch_scc1 3f\n\t"
+      "s_cmp_lg_u64 %[todo], 0\n\t"
+      "s_cbranch_scc1 1b\n\t"
+      "s_branch 2f\n"
+      "3:\n\t"
+      "s_mov_b32 %[sl], m0\n"
+      "2:\n"
+      : [todo] "+s"(todo), [tc] "+s"(tc), [tb] "+v"(tb), [sl] "+s"(sl), [d] "=&v"(d), [t] "=&v"(t)
+      : [f] "v"(f)
+      : "m0", "scc");
+  Tc = __int_as_float(tc);
+  T_before = __int_as_float(tb);
+  return sl;
+}
+
+// FAST (default; DVGO_TUNE_DENSITY_FWD 0 restores round 2's body for A/B): the eight corner loads of a sample are in
+// flight together as four 8-byte z-pairs (common.h: dvgo_tri_value_c1; the plain form compiles to eight dependent
+// load -> wait -> fma round trips) and the occupancy byte of the NEXT chunk is requested before this chunk's density
+// loads, so a chunk pays one memory round trip instead of nine.  Same arithmetic in the same order: same bits.
+template <bool FAST>
 __global__ void __launch_bounds__(DVGO_BLOCK)
 march_density_kernel(const float* __restrict__ rays_start, const float* __restrict__ rays_dir,
                      const int64_t* __restrict__ n_steps, const int64_t* __restrict__ cum,
@@ -162,21 +215,44 @@ march_density_kernel(const float* __restrict__ rays_start, const float* __restri
   const float dx = rays_dir[3 * ray], dy = rays_dir[3 * ray + 1], dz = rays_dir[3 * ray + 2];
   const int64_t YZ = (int64_t)P.Y * P.Z;
   const bool filt = P.thres > 0.0f;
+  const bool pairs = FAST && P.Z >= 2;
 
-  float Tc = 1.0f;
-  int c2 = 0, c3 = 0;
-  for (int base = 0; base < ns; base += 64) {
-    const int step = base + lane;
-    const bool act = step < ns;
+  // in-box test and occupancy byte of one step (the byte load is what gets requested a chunk ahead)
+  auto probe = [&](int step, float& px, float& py, float& pz, uint8_t& mb) -> bool {
     const float dist = march_dist(P.stepdist, step);
-    const float px = fmaf(dx, dist, sx), py = fmaf(dy, dist, sy), pz = fmaf(dz, dist, sz);
-    bool keep = act && !((P.mnx > px) | (P.mny > py) | (P.mnz > pz) | (P.mxx < px) | (P.mxy < py) | (P.mxz < pz));
+    px = fmaf(dx, dist, sx); py = fmaf(dy, dist, sy); pz = fmaf(dz, dist, sz);
+    bool keep = (step < ns) && !((P.mnx > px) | (P.mny > py) | (P.mnz > pz) | (P.mxx < px) | (P.mxy < py) | (P.mxz < pz));
+    mb = 1;
     if (mask != nullptr && keep) {
       const int i = (int)roundf(fmaf(px, P.scx, P.shx));
       const int j = (int)roundf(fmaf(py, P.scy, P.shy));
       const int k = (int)roundf(fmaf(pz, P.scz, P.shz));
       keep = (0 <= i) & (i < P.mX) & (0 <= j) & (j < P.mY) & (0 <= k) & (k < P.mZ);
-      if (keep) keep = mask[((int64_t)i * P.mY + j) * P.mZ + k] != 0;
+      if (keep) mb = mask[((int64_t)i * P.mY + j) * P.mZ + k];
+    }
+    return keep;
+  };
+
+  float Tc = 1.0f;
+  int c2 = 0, c3 = 0;
+  float npx = 0.f, npy = 0.f, npz = 0.f;
+  uint8_t nmb = 0;
+  bool nkeep = false;
+  if (FAST) nkeep = probe(lane, npx, npy, npz, nmb);
+  for (int base = 0; base < ns; base += 64) {
+    const int step = base + lane;
+    float px, py, pz;
+    bool keep;
+    if (FAST) {
+      px = npx; py = npy; pz = npz;
+      const uint8_t mb = nmb;
+      const bool k0 = nkeep;
+      if (base + 64 < ns) nkeep = probe(step + 64, npx, npy, npz, nmb);      // next chunk's byte: in flight under this chunk
+      keep = k0 && mb != 0;
+    } else {
+      uint8_t mb;
+      keep = probe(step, px, py, pz, mb);
+      keep = keep && mb != 0;
     }
     float e = 0.f, a = 0.f;
     TriSetup t;
@@ -184,16 +260,20 @@ march_density_kernel(const float* __restrict__ rays_start, const float* __restri
     if (keep) {
       t = dvgo_tri_setup(px, py, pz, P.mnx, P.mny, P.mnz, P.mxx, P.mxy, P.mxz, P.X, P.Y, P.Z);
       float d = 0.f;
+      if (pairs) {
+        d = dvgo_tri_value_c1(density, t, P.X, P.Y, P.Z);
+      } else {
 #pragma unroll
-      for (int n = 0; n < 8; ++n) {
-        if (dvgo_tri_inb(t, n, P.X, P.Y, P.Z)) {
-          const int64_t off = (int64_t)(t.i0 + ((n >> 2) & 1)) * YZ + (int64_t)(t.j0 + ((n >> 1) & 1)) * P.Z +
-                              (t.k0 + (n & 1));
-          d = fmaf(density[off], dvgo_tri_weight(t, n), d);
+        for (int n = 0; n < 8; ++n) {
+          if (dvgo_tri_inb(t, n, P.X, P.Y, P.Z)) {
+            const int64_t off = (int64_t)(t.i0 + ((n >> 2) & 1)) * YZ + (int64_t)(t.j0 + ((n >> 1) & 1)) * P.Z +
+                                (t.k0 + (n & 1));
+            d = fmaf(density[off], dvgo_tri_weight(t, n), d);
+          }
         }
       }
       e = expf(d + P.act_shift);
-      a = 1.0f - powf(1.0f + e, -P.interval);
+      a = 1.0f - dvgo_pow_neg(1.0f + e, -P.interval);
       if (filt) keep = a > P.thres;
     }
     // transmittance, in the reference's order and precision (K12, render_utils_kernel.cu:448-454):
@@ -202,17 +282,22 @@ march_density_kernel(const float* __restrict__ rays_start, const float* __restri
     // never enters compositing): each step is one exec-masked multiply on lane j and a v_readlane of the result,
     // so T, the weights and every threshold decision are bit-identical to the serial code.
     const double f = 1.0 - (double)a + 1e-10;
-    float T_before = 1.0f, T_after = 1.0f;
-    unsigned long long todo = __ballot(keep);
+    float T_before = 1.0f;
     int stop_lane = -1;
-    while (todo) {
-      const int j = __ffsll((long long)todo) - 1;
-      todo &= todo - 1;
-      if (lane == j) { T_before = Tc; T_after = (float)((double)Tc * f); }
-      Tc = dvgo_readlane_f(T_after, j);
-      // (double)T < 1e-3  <=>  T < 1e-3f for floats (1e-3f is the float just above the double 1e-3); T >= 0, so the
-      // ordered-unsigned compare of the bit patterns is the same test and stays on the scalar unit
-      if (__float_as_uint(Tc) < 0x3A83126Fu) { stop_lane = j; break; }
+    if (FAST) {
+      stop_lane = chain_walk(__ballot(keep), f, Tc, T_before);
+    } else {
+      unsigned long long todo = __ballot(keep);
+      while (todo) {
+        const int j = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        float T_after = 1.0f;
+        if (lane == j) { T_before = Tc; T_after = (float)((double)Tc * f); }
+        Tc = dvgo_readlane_f(T_after, j);
+        // (double)T < 1e-3  <=>  T < 1e-3f for floats (1e-3f is the float just above the double 1e-3); T >= 0, so the
+        // ordered-unsigned compare of the bit patterns is the same test and stays on the scalar unit
+        if (__float_as_uint(Tc) < 0x3A83126Fu) { stop_lane = j; break; }
+      }
     }
     const bool stop = stop_lane >= 0;
     const bool valid2 = keep && (!stop || lane <= stop_lane);
@@ -280,7 +365,11 @@ march_hit_kernel(const float* __restrict__ rays_start, const float* __restrict__
 // ids / weight / alpha of its sample.  weight = T * alpha is the product march_density formed for its filter, from
 // the same two floats, so no second record array travels between the two kernels.
 // ----------------------------------------------------------------------------------
-template <int CVEC, int CS = 0>   // CVEC > 0: channels-last, C == 4*CVEC, 16-B aligned; CS > 0: channels-last, C == CS, dword
+// GRP (vector rows only): corner rows requested together by a lane whose 8 corners are all in range (every sample
+// but those on the upper faces).  Written corner by corner -- `if (in range) { load row; fma }` -- the kernel makes
+// eight dependent round trips of three 16-byte loads each; with GRP = 4 / 8 it makes two / one of 12 / 24 loads,
+// and the fma chain still runs in corner order 0..7: same bits.  GRP = 1: round 2's body (A/B).
+template <int CVEC, int CS = 0, int GRP = 1>   // CVEC > 0: channels-last, C == 4*CVEC, 16-B aligned; CS > 0: channels-last, C == CS, dword
 __global__ void __launch_bounds__(DVGO_BLOCK)   // loads (rows of 3 / 9 floats: coarse stage, LLFF); both 0: generic strides
 march_gather_kernel(const dvgo_rec2_t* __restrict__ rec2, const int32_t* __restrict__ n2, const int64_t* __restrict__ n_steps,
                     const int64_t* __restrict__ cum, int64_t rec_stride, const int64_t* __restrict__ off3,
@@ -298,11 +387,13 @@ march_gather_kernel(const dvgo_rec2_t* __restrict__ rec2, const int32_t* __restr
   const float sx = rays_start[3 * r], sy = rays_start[3 * r + 1], sz = rays_start[3 * r + 2];
   const float dx = rays_dir[3 * r], dy = rays_dir[3 * r + 1], dz = rays_dir[3 * r + 2];
   const unsigned long long lt = lanemask_lt(lane);
+  dvgo_rec2_t nrec;                       // the next chunk's records are requested before this chunk's corner rows
+  nrec.step = 0; nrec.exp_d = 0.f; nrec.alpha = 0.f; nrec.T = 0.f;
+  if (lane < c2) nrec = rec2[cs0 + lane];
   for (int lo = 0; lo < c2; lo += 64) {
     const int j = lo + lane;
-    dvgo_rec2_t rec;
-    rec.step = 0; rec.exp_d = 0.f; rec.alpha = 0.f; rec.T = 0.f;
-    if (j < c2) rec = rec2[cs0 + j];
+    const dvgo_rec2_t rec = nrec;
+    if (j + 64 < c2) nrec = rec2[cs0 + j + 64];       // (lanes past the ray's end keep a stale record: `kept` masks them)
     const bool kept = (j < c2) && (rec.step < 0);
     const unsigned long long m = __ballot(kept);
     const int64_t i = out + __popcll(m & lt);
@@ -330,6 +421,31 @@ march_gather_kernel(const dvgo_rec2_t* __restrict__ rec2, const int32_t* __restr
       float4 acc[CVEC > 0 ? CVEC : 1];
 #pragma unroll
       for (int c = 0; c < CVEC; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+      bool all_in = GRP > 1;
+#pragma unroll
+      for (int n = 0; n < 8; ++n) all_in = all_in && ok[n];
+      if (all_in) {
+#pragma unroll
+        for (int g = 0; g < 8; g += (GRP > 1 ? GRP : 8)) {
+          float4 v[GRP > 1 ? GRP : 1][CVEC > 0 ? CVEC : 1];
+#pragma unroll
+          for (int n = 0; n < GRP; ++n) {
+            const float4* p = reinterpret_cast<const float4*>(k0 + off[g + n]);
+#pragma unroll
+            for (int c = 0; c < CVEC; ++c) v[n][c] = p[c];
+          }
+#pragma unroll
+          for (int n = 0; n < GRP; ++n) {
+#pragma unroll
+            for (int c = 0; c < CVEC; ++c) {
+              acc[c].x = fmaf(v[n][c].x, w[g + n], acc[c].x);
+              acc[c].y = fmaf(v[n][c].y, w[g + n], acc[c].y);
+              acc[c].z = fmaf(v[n][c].z, w[g + n], acc[c].z);
+              acc[c].w = fmaf(v[n][c].w, w[g + n], acc[c].w);
+            }
+          }
+        }
+      } else
 #pragma unroll
       for (int n = 0; n < 8; ++n) {
         if (ok[n]) {
@@ -700,7 +816,7 @@ march_density_bwd_kernel(const dvgo_rec2_t* __restrict__ rec2, const int32_t* __
       const float gt = gw * rec.T;
       const float one_minus = 1.0f - rec.alpha;
       const float g_alpha = (float)((double)gt - (double)my_acc / ((double)one_minus + 1e-10));
-      double v = fmin((double)rec.exp_d, 1e10) * (double)powf(1.0f + rec.exp_d, -P.interval - 1.0f);
+      double v = fmin((double)rec.exp_d, 1e10) * (double)dvgo_pow_neg(1.0f + rec.exp_d, -P.interval - 1.0f);
       v = v * (double)P.interval;
       v = v * (double)g_alpha;
       g_d = (float)v;
@@ -798,9 +914,14 @@ int dvgo_march_density(const float* rays_start, const float* rays_dir, const int
   if (!dvgo_fits(n_rays * 64)) return DVGO_ERANGE;
   const MarchParams P = make_params(xyz_min, xyz_max, stepdist, xyz2ijk_scale, xyz2ijk_shift, mX, mY, mZ,
                                     X, Y, Z, act_shift, interval, fast_color_thres);
-  march_density_kernel<<<dvgo_blocks(n_rays * 64, DVGO_BLOCK), DVGO_BLOCK, 0, (hipStream_t)stream>>>(
-      rays_start, rays_dir, n_steps, n_steps_cumsum, rec_stride, n_rays, mask, density, P, rec2, n2, n3,
-      alphainv_last, brick_cnt);
+  if (g_tuning[DVGO_TUNE_DENSITY_FWD])
+    march_density_kernel<true><<<dvgo_blocks(n_rays * 64, DVGO_BLOCK), DVGO_BLOCK, 0, (hipStream_t)stream>>>(
+        rays_start, rays_dir, n_steps, n_steps_cumsum, rec_stride, n_rays, mask, density, P, rec2, n2, n3,
+        alphainv_last, brick_cnt);
+  else
+    march_density_kernel<false><<<dvgo_blocks(n_rays * 64, DVGO_BLOCK), DVGO_BLOCK, 0, (hipStream_t)stream>>>(
+        rays_start, rays_dir, n_steps, n_steps_cumsum, rec_stride, n_rays, mask, density, P, rec2, n2, n3,
+        alphainv_last, brick_cnt);
   DVGO_LAUNCH_CHECK();
   return 0;
 }
@@ -839,16 +960,19 @@ int dvgo_march_gather(const dvgo_rec2_t* rec2, const int32_t* n2, const int64_t*
   const int blocks = dvgo_blocks(n_rays * 64, DVGO_BLOCK);
   const bool vec = (sC == 1) && (C % 4 == 0) && (sX % 4 == 0) && (sY % 4 == 0) && (sZ % 4 == 0) &&
                    ((((uintptr_t)k0) & 15) == 0) && ((((uintptr_t)feat) & 15) == 0);
-#define DVGO_GATHER(CV, CSS)                                                                                      \
-  march_gather_kernel<CV, CSS><<<blocks, DVGO_BLOCK, 0, s>>>(rec2, n2, n_steps, n_steps_cumsum, rec_stride, off3, \
+#define DVGO_GATHER(CV, CSS, G)                                                                                      \
+  march_gather_kernel<CV, CSS, G><<<blocks, DVGO_BLOCK, 0, s>>>(rec2, n2, n_steps, n_steps_cumsum, rec_stride, off3, \
       n_rays, rays_start, rays_dir, P, k0, C, sC, sX, sY, sZ, ray_id, step_id, weights, alpha, feat)
-  if (vec && C == 12) DVGO_GATHER(3, 0);
-  else if (vec && C == 4) DVGO_GATHER(1, 0);
-  else if (vec && C == 8) DVGO_GATHER(2, 0);
-  else if (vec && C == 16) DVGO_GATHER(4, 0);
-  else if (sC == 1 && C == 9) DVGO_GATHER(0, 9);
-  else if (sC == 1 && C == 3) DVGO_GATHER(0, 3);
-  else DVGO_GATHER(0, 0);
+  const int grp = g_tuning[DVGO_TUNE_GATHER];
+  if (vec && C == 12 && grp == 8) DVGO_GATHER(3, 0, 8);
+  else if (vec && C == 12 && grp >= 1) DVGO_GATHER(3, 0, 4);
+  else if (vec && C == 12) DVGO_GATHER(3, 0, 1);
+  else if (vec && C == 4) DVGO_GATHER(1, 0, 8);
+  else if (vec && C == 8) DVGO_GATHER(2, 0, 4);
+  else if (vec && C == 16) DVGO_GATHER(4, 0, 4);
+  else if (sC == 1 && C == 9) DVGO_GATHER(0, 9, 1);
+  else if (sC == 1 && C == 3) DVGO_GATHER(0, 3, 1);
+  else DVGO_GATHER(0, 0, 1);
 #undef DVGO_GATHER
   DVGO_LAUNCH_CHECK();
   return 0;

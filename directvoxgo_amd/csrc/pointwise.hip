@@ -22,7 +22,7 @@ maskcache_lookup_kernel(const uint8_t* __restrict__ world, const float* __restri
 // in the body, scalar tail.
 __device__ __forceinline__ void raw2alpha_one(float d, float shift, float interval, float& e, float& a) {
   e = expf(d + shift);                 // may be +inf
-  a = 1.0f - powf(1.0f + e, -interval);
+  a = 1.0f - dvgo_pow_neg(1.0f + e, -interval);
 }
 
 __global__ void __launch_bounds__(DVGO_BLOCK)
@@ -51,7 +51,7 @@ raw2alpha_kernel(const float* __restrict__ density, float shift, float interval,
 
 // K10 :402-405.  (float)( min((double)e, 1e10) * (double)powf(1+e, -interval-1) * interval * g )
 __device__ __forceinline__ float raw2alpha_bwd_one(float e, float g, float interval) {
-  double v = fmin((double)e, 1e10) * (double)powf(1.0f + e, -interval - 1.0f);
+  double v = fmin((double)e, 1e10) * (double)dvgo_pow_neg(1.0f + e, -interval - 1.0f);
   v = v * (double)interval;
   v = v * (double)g;
   return (float)v;

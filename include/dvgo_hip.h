@@ -45,6 +45,8 @@ int dvgo_abi_version(void);
  * measured variants).  key: one of DVGO_TUNE_*; returns DVGO_EINVAL for an unknown key. */
 #define DVGO_TUNE_FEAT_BWD    0   /* 0 = one atomic per (sample,corner,channel); 1 = LDS de-duplicated rows */
 #define DVGO_TUNE_DENSITY_BWD 1   /* 0 = direct atomics; 1 = LDS de-duplicated */
+#define DVGO_TUNE_DENSITY_FWD 2   /* march_density: 1 = corner loads in flight together as z-pairs + occupancy byte a chunk ahead; 0 = round 2's body */
+#define DVGO_TUNE_GATHER      3   /* march_gather: 1 = corner rows requested four at a time; 0 = one corner per round trip */
 #define DVGO_TUNE_COUNT       8
 int dvgo_set_tuning(int key, int value);
 
