@@ -147,6 +147,31 @@ __device__ __forceinline__ void dvgo_sample_pos(const float* __restrict__ start,
   pz = fmaf(dir[3 * r + 2], dist, start[3 * r + 2]);
 }
 
+// K1 + K2 + K3 of one ray (render_utils_kernel.cu:11-73), expression for expression what sampling.hip's ray_setup_kernel
+// computes (same flags, hence the same bits): slab test -> t_min / t_max, step count, start point and unit direction.
+struct RaySetup { float tmin, tmax, sx, sy, sz, dx, dy, dz; int64_t n; };
+__device__ __forceinline__ RaySetup dvgo_ray_setup(float ox, float oy, float oz, float dx, float dy, float dz,
+                                                   float mnx, float mny, float mnz, float mxx, float mxy, float mxz,
+                                                   float near, float far, float stepdist) {
+  RaySetup R;
+  // K1 :23-33
+  const float vx = (dx == 0) ? (float)1e-6 : dx;
+  const float vy = (dy == 0) ? (float)1e-6 : dy;
+  const float vz = (dz == 0) ? (float)1e-6 : dz;
+  const float ax = (mxx - ox) / vx, ay = (mxy - oy) / vy, az = (mxz - oz) / vz;
+  const float bx = (mnx - ox) / vx, by = (mny - oy) / vy, bz = (mnz - oz) / vz;
+  R.tmin = fmaxf(fminf(fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz)), far), near);
+  R.tmax = fmaxf(fminf(fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)), far), near);
+  // K2 :47  max(ceil((t_max - t_min) / stepdist), 1.) -> int64
+  const float c = ceilf((R.tmax - R.tmin) / stepdist);
+  R.n = (int64_t)fmax((double)c, 1.);
+  // K3 :62-71
+  const float rnorm = sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+  R.sx = fmaf(dx, R.tmin, ox); R.sy = fmaf(dy, R.tmin, oy); R.sz = fmaf(dz, R.tmin, oz);
+  R.dx = dx / rnorm; R.dy = dy / rnorm; R.dz = dz / rnorm;
+  return R;
+}
+
 // distance of sample `step` along its ray in the fused march:
 //   K6 (render_utils_kernel.cu:178)  stepdist * i_step                -- rays_start / unit rays_dir   (stepdist > 0)
 //   K7 (render_utils_kernel.cu:254)  (float)i_step / (N_samples - 1)  -- rays_o / un-normalised rays_d (stepdist < 0)

@@ -66,7 +66,9 @@ struct MarchParams {
   int mX, mY, mZ;
   int X, Y, Z;
   float act_shift, interval, thres;
-};
+  int experiment;          // timing experiments only (DVGO_TUNE_EXPERIMENT; results are WRONG when non-zero): 1 no transmittance walk,
+};                         // 2 no exp/pow, 4 no density loads, 8 no occupancy bytes
+
 
 // ----------------------------------------------------------------------------------
 // Brick lists (brick.hip): every sample that entered compositing is listed by each 8x8x8 brick that holds one of
@@ -199,20 +201,37 @@ __device__ __forceinline__ int chain_walk(unsigned long long todo, double f, flo
 // loads, so a chunk pays one memory round trip instead of nine.  Same arithmetic in the same order: same bits.
 template <bool FAST>
 __global__ void __launch_bounds__(DVGO_BLOCK)
-march_density_kernel(const float* __restrict__ rays_start, const float* __restrict__ rays_dir,
-                     const int64_t* __restrict__ n_steps, const int64_t* __restrict__ cum,
+march_density_kernel(float* __restrict__ rays_start, float* __restrict__ rays_dir,
+                     int64_t* __restrict__ n_steps, const int64_t* __restrict__ cum,
                      int64_t rec_stride, int64_t n_rays, const uint8_t* __restrict__ mask,
                      const float* __restrict__ density, MarchParams P,
                      dvgo_rec2_t* __restrict__ rec2,
                      int32_t* __restrict__ n2, int32_t* __restrict__ n3,
-                     float* __restrict__ alphainv_last, int32_t* __restrict__ brick_cnt) {
+                     float* __restrict__ alphainv_last, int32_t* __restrict__ brick_cnt,
+                     const float* __restrict__ rays_o, const float* __restrict__ rays_d, float near, float far) {
   const int64_t ray = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   if (ray >= n_rays) return;
-  const int ns = __builtin_amdgcn_readfirstlane((int)n_steps[ray]);
-  const int64_t cs0 = rec_base(cum, n_steps, rec_stride, ray);
-  const float sx = rays_start[3 * ray], sy = rays_start[3 * ray + 1], sz = rays_start[3 * ray + 2];
-  const float dx = rays_dir[3 * ray], dy = rays_dir[3 * ray + 1], dz = rays_dir[3 * ray + 2];
+  int ns;
+  float sx, sy, sz, dx, dy, dz;
+  if (rays_o != nullptr) {
+    // K1-K3 of this ray right here (one launch less than a separate ray_setup kernel); lane 0 leaves the start point, the
+    // unit direction and the step count for the kernels behind
+    const RaySetup R = dvgo_ray_setup(rays_o[3 * ray], rays_o[3 * ray + 1], rays_o[3 * ray + 2], rays_d[3 * ray], rays_d[3 * ray + 1],
+                                      rays_d[3 * ray + 2], P.mnx, P.mny, P.mnz, P.mxx, P.mxy, P.mxz, near, far, P.stepdist);
+    sx = R.sx; sy = R.sy; sz = R.sz; dx = R.dx; dy = R.dy; dz = R.dz;
+    ns = __builtin_amdgcn_readfirstlane((int)R.n);
+    if (lane == 0) {
+      n_steps[ray] = R.n;
+      rays_start[3 * ray] = sx; rays_start[3 * ray + 1] = sy; rays_start[3 * ray + 2] = sz;
+      rays_dir[3 * ray] = dx; rays_dir[3 * ray + 1] = dy; rays_dir[3 * ray + 2] = dz;
+    }
+  } else {
+    ns = __builtin_amdgcn_readfirstlane((int)n_steps[ray]);
+    sx = rays_start[3 * ray]; sy = rays_start[3 * ray + 1]; sz = rays_start[3 * ray + 2];
+    dx = rays_dir[3 * ray]; dy = rays_dir[3 * ray + 1]; dz = rays_dir[3 * ray + 2];
+  }
+  const int64_t cs0 = (rays_o != nullptr) ? ray * rec_stride : rec_base(cum, n_steps, rec_stride, ray);
   const int64_t YZ = (int64_t)P.Y * P.Z;
   const bool filt = P.thres > 0.0f;
   const bool pairs = FAST && P.Z >= 2;
@@ -228,7 +247,7 @@ march_density_kernel(const float* __restrict__ rays_start, const float* __restri
       const int j = (int)roundf(fmaf(py, P.scy, P.shy));
       const int k = (int)roundf(fmaf(pz, P.scz, P.shz));
       keep = (0 <= i) & (i < P.mX) & (0 <= j) & (j < P.mY) & (0 <= k) & (k < P.mZ);
-      if (keep) mb = mask[((int64_t)i * P.mY + j) * P.mZ + k];
+      if (keep && !(P.experiment & 8)) mb = mask[((int64_t)i * P.mY + j) * P.mZ + k];
     }
     return keep;
   };
@@ -260,7 +279,9 @@ march_density_kernel(const float* __restrict__ rays_start, const float* __restri
     if (keep) {
       t = dvgo_tri_setup(px, py, pz, P.mnx, P.mny, P.mnz, P.mxx, P.mxy, P.mxz, P.X, P.Y, P.Z);
       float d = 0.f;
-      if (pairs) {
+      if (P.experiment & 4) {
+        d = t.wx0 * 4.0f - 2.0f;
+      } else if (pairs) {
         d = dvgo_tri_value_c1(density, t, P.X, P.Y, P.Z);
       } else {
 #pragma unroll
@@ -272,8 +293,11 @@ march_density_kernel(const float* __restrict__ rays_start, const float* __restri
           }
         }
       }
-      e = expf(d + P.act_shift);
-      a = 1.0f - dvgo_pow_neg(1.0f + e, -P.interval);
+      if (P.experiment & 2) { e = d * 0.01f; a = e * 0.5f; }
+      else {
+        e = expf(d + P.act_shift);
+        a = 1.0f - dvgo_pow_neg(1.0f + e, -P.interval);
+      }
       if (filt) keep = a > P.thres;
     }
     // transmittance, in the reference's order and precision (K12, render_utils_kernel.cu:448-454):
@@ -284,7 +308,9 @@ march_density_kernel(const float* __restrict__ rays_start, const float* __restri
     const double f = 1.0 - (double)a + 1e-10;
     float T_before = 1.0f;
     int stop_lane = -1;
-    if (FAST) {
+    if (P.experiment & 1) {
+      T_before = 0.5f;
+    } else if (FAST) {
       stop_lane = chain_walk(__ballot(keep), f, Tc, T_before);
     } else {
       unsigned long long todo = __ballot(keep);
@@ -508,12 +534,26 @@ march_composite_kernel(const float* __restrict__ weights, const float* __restric
   if (ray >= n_rays) return;
   const int64_t b = off3[ray], e = off3[ray + 1];
   float r = 0.f, g = 0.f, bl = 0.f, dsum = 0.f;
-  for (int64_t i = b + lane; i < e; i += 64) {
-    const float w = weights[i];
-    r = fmaf(w, rgb[3 * i + 0], r);
-    g = fmaf(w, rgb[3 * i + 1], g);
-    bl = fmaf(w, rgb[3 * i + 2], bl);
-    if (depth) dsum = fmaf(w, (float)step_id[i], dsum);
+  // four 64-sample slices per round, all of their loads requested before the first fma (a ray of <= 256 samples makes
+  // one memory round trip instead of four); a lane past the end reads the ray's last sample with weight 0: r + 0 * x = r
+  for (int64_t i0 = b; i0 < e; i0 += 256) {
+    float w[4], c0[4], c1[4], c2[4], sd[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t i = i0 + lane + 64 * u;
+      const int64_t ic = i < e ? i : e - 1;
+      w[u] = weights[ic];
+      c0[u] = rgb[3 * ic + 0]; c1[u] = rgb[3 * ic + 1]; c2[u] = rgb[3 * ic + 2];
+      sd[u] = depth ? (float)step_id[ic] : 0.f;
+      if (i >= e) w[u] = 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      r = fmaf(w[u], c0[u], r);
+      g = fmaf(w[u], c1[u], g);
+      bl = fmaf(w[u], c2[u], bl);
+      if (depth) dsum = fmaf(w[u], sd[u], dsum);
+    }
   }
   r = wave_sum(r); g = wave_sum(g); bl = wave_sum(bl);
   if (depth) dsum = wave_sum(dsum);
@@ -883,6 +923,7 @@ static MarchParams make_params(const float* mn, const float* mx, float stepdist,
   P.mX = mX; P.mY = mY; P.mZ = mZ;
   P.X = X; P.Y = Y; P.Z = Z;
   P.act_shift = act_shift; P.interval = interval; P.thres = thres;
+  P.experiment = g_tuning[DVGO_TUNE_EXPERIMENT];
   return P;
 }
 
@@ -897,19 +938,21 @@ int dvgo_set_tuning(int key, int value) {
 // NOTE: xyz_min / xyz_max / xyz2ijk_scale / xyz2ijk_shift are HOST pointers (3 floats each)
 // in the fused entry points: they are model constants and travel as kernel arguments.
 
-int dvgo_march_density(const float* rays_start, const float* rays_dir, const int64_t* n_steps,
+int dvgo_march_density(float* rays_start, float* rays_dir, int64_t* n_steps,
                        const int64_t* n_steps_cumsum, int64_t rec_stride, int64_t n_rays, const float* xyz_min,
                        const float* xyz_max, float stepdist, const uint8_t* mask, int mX, int mY, int mZ,
                        const float* xyz2ijk_scale, const float* xyz2ijk_shift, const float* density,
                        int X, int Y, int Z, float act_shift, float interval, float fast_color_thres,
                        dvgo_rec2_t* rec2, int32_t* n2, int32_t* n3,
-                       float* alphainv_last, int32_t* brick_cnt, void* stream) {
+                       float* alphainv_last, int32_t* brick_cnt, const float* rays_o, const float* rays_d, float near,
+                       float far, void* stream) {
   if (n_rays < 0 || X <= 0 || Y <= 0 || Z <= 0) return DVGO_EINVAL;
   if (n_rays == 0) return 0;
   if (!rays_start || !rays_dir || !n_steps || !xyz_min || !xyz_max || !density ||
       !rec2 || !n2 || !n3 || !alphainv_last)
     return DVGO_EINVAL;
   if (!n_steps_cumsum && rec_stride <= 0) return DVGO_EINVAL;
+  if (rays_o && (!rays_d || rec_stride <= 0 || stepdist <= 0.0f)) return DVGO_EINVAL;   // in-kernel ray setup: fixed-stride records, metric steps
   if (mask && (!xyz2ijk_scale || !xyz2ijk_shift || mX <= 0 || mY <= 0 || mZ <= 0)) return DVGO_EINVAL;
   if (!dvgo_fits(n_rays * 64)) return DVGO_ERANGE;
   const MarchParams P = make_params(xyz_min, xyz_max, stepdist, xyz2ijk_scale, xyz2ijk_shift, mX, mY, mZ,
@@ -917,11 +960,11 @@ int dvgo_march_density(const float* rays_start, const float* rays_dir, const int
   if (g_tuning[DVGO_TUNE_DENSITY_FWD])
     march_density_kernel<true><<<dvgo_blocks(n_rays * 64, DVGO_BLOCK), DVGO_BLOCK, 0, (hipStream_t)stream>>>(
         rays_start, rays_dir, n_steps, n_steps_cumsum, rec_stride, n_rays, mask, density, P, rec2, n2, n3,
-        alphainv_last, brick_cnt);
+        alphainv_last, brick_cnt, rays_o, rays_d, near, far);
   else
     march_density_kernel<false><<<dvgo_blocks(n_rays * 64, DVGO_BLOCK), DVGO_BLOCK, 0, (hipStream_t)stream>>>(
         rays_start, rays_dir, n_steps, n_steps_cumsum, rec_stride, n_rays, mask, density, P, rec2, n2, n3,
-        alphainv_last, brick_cnt);
+        alphainv_last, brick_cnt, rays_o, rays_d, near, far);
   DVGO_LAUNCH_CHECK();
   return 0;
 }

@@ -126,12 +126,11 @@ class _FusedMarch(torch.autograd.Function):
         ndc = cfg.ndc_samples > 0
         stride = cfg.ndc_samples if ndc else _rec_stride(cfg, N)
 
+        setup_in_march = (not ndc) and stride > 0        # K1-K3 inside march_density: one launch less
         if ndc:
             n_steps = torch.full((N,), cfg.ndc_samples, dtype=torch.int64, device=dev)
             start, dirs = rays_o, rays_d
         else:
-            t_min = torch.empty(N, dtype=torch.float32, device=dev)
-            t_max = torch.empty_like(t_min)
             n_steps = torch.empty(N, dtype=torch.int64, device=dev)
             start = torch.empty((N, 3), dtype=torch.float32, device=dev)
             dirs = torch.empty((N, 3), dtype=torch.float32, device=dev)
@@ -141,7 +140,9 @@ class _FusedMarch(torch.autograd.Function):
         last = torch.empty(N, dtype=torch.float32, device=dev)
         off3 = torch.empty(N + 1, dtype=torch.int64, device=dev)
         with L.device_of(rays_o):
-            if not ndc:
+            if not ndc and not setup_in_march:
+                t_min = torch.empty(N, dtype=torch.float32, device=dev)
+                t_max = torch.empty_like(t_min)
                 L.call('dvgo_sample_pts_prepare', ptr(rays_o), ptr(rays_d), ptr(cfg.xyz_min_t), ptr(cfg.xyz_max_t),
                        _flt(cfg.near), _flt(cfg.far), _flt(cfg.stepdist), _i64(N), ptr(t_min), ptr(t_max),
                        ptr(n_steps), ptr(cum), ptr(start), ptr(dirs), st)
@@ -173,7 +174,8 @@ class _FusedMarch(torch.autograd.Function):
                    cfg.xyz_min_h, cfg.xyz_max_h, _flt(cfg.stepdist), ptr(mask), _int(mshape[0]), _int(mshape[1]),
                    _int(mshape[2]), cfg.scale_h, cfg.shift_h, ptr(density), _int(X), _int(Y), _int(Z),
                    _flt(cfg.act_shift), _flt(cfg.interval), _flt(cfg.thres), ptr(rec2), ptr(n2), ptr(n3),
-                   ptr(last), ptr(brick_cnt), st)
+                   ptr(last), ptr(brick_cnt), ptr(rays_o if setup_in_march else None), ptr(rays_d if setup_in_march else None),
+                   _flt(cfg.near), _flt(cfg.far), st)
             n_entries = 0
             if N <= 16384:              # both scans in one launch (one workgroup each)
                 L.call('dvgo_march_scans', ptr(n3), _i64(N), ptr(off3), ptr(brick_cnt), _int(nb if bricks else 0),

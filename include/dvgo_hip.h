@@ -47,6 +47,7 @@ int dvgo_abi_version(void);
 #define DVGO_TUNE_DENSITY_BWD 1   /* 0 = direct atomics; 1 = LDS de-duplicated */
 #define DVGO_TUNE_DENSITY_FWD 2   /* march_density: 1 = corner loads in flight together as z-pairs + occupancy byte a chunk ahead; 0 = round 2's body */
 #define DVGO_TUNE_GATHER      3   /* march_gather: 1 = corner rows requested four at a time; 0 = one corner per round trip */
+#define DVGO_TUNE_EXPERIMENT  4   /* march_density timing experiments (bit mask, results wrong when non-zero; tools/fwd_ab.py) */
 #define DVGO_TUNE_COUNT       8
 int dvgo_set_tuning(int key, int value);
 
@@ -194,8 +195,8 @@ int dvgo_segment_sum(const float* src, const int64_t* index, int64_t M, int C,
  * --------------------------------------------------------------------------------- */
 typedef struct { int32_t step; float exp_d; float alpha; float T; } dvgo_rec2_t;     /* 16 B */
 
-int dvgo_march_density(const float* rays_start, const float* rays_dir,
-                       const int64_t* n_steps, const int64_t* n_steps_cumsum, int64_t rec_stride,
+int dvgo_march_density(float* rays_start, float* rays_dir,
+                       int64_t* n_steps, const int64_t* n_steps_cumsum, int64_t rec_stride,
                        int64_t n_rays,
                        const float* xyz_min, const float* xyz_max, float stepdist,
                        const uint8_t* mask, int mX, int mY, int mZ,
@@ -207,6 +208,10 @@ int dvgo_march_density(const float* rays_start, const float* rays_dir,
                        int32_t* brick_cnt /* NULL, or [dvgo_n_bricks(X,Y,Z)] zero-initialised counters: the samples
                                              that entered compositing are counted per brick for the backward's
                                              owner-computes scatter (see "Brick scatter" below) */,
+                       const float* rays_o, const float* rays_d, float near, float far
+                                          /* rays_o != NULL (fixed-stride records, stepdist > 0): K1-K3 of
+                                             dvgo_sample_pts_prepare are computed by this launch and rays_start / rays_dir /
+                                             n_steps are OUTPUTS; NULL: they are inputs */,
                        void* stream);
 
 /* dvgo_march_hit: hit[r] = 1 iff ray r has an in-box sample whose nearest occupancy voxel is set -- the fused

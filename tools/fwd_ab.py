@@ -23,6 +23,8 @@ ap.add_argument('--train', action='store_true', help='training forward (brick co
 ap.add_argument('--density', default='0,1')
 ap.add_argument('--gather', default='0,4,8')
 ap.add_argument('--workloads', default='roofline,lego')
+ap.add_argument('--same-ray', action='store_true', help='every ray = ray 0 (all waves touch the same voxels: cache hits, same address pattern per instruction)')
+ap.add_argument('--experiment', default='0', help='comma list of DVGO_TUNE_EXPERIMENT masks (non-zero: timing only, no output check)')
 args = ap.parse_args()
 NAMES = ['dvgo_sample_pts_prepare', 'dvgo_march_density', 'dvgo_march_scans', 'dvgo_exclusive_scan_i32', 'dvgo_march_gather',
          'dvgo_march_composite']
@@ -40,6 +42,9 @@ for workload in args.workloads.split(','):
     with torch.no_grad():
         m.density.copy_(sc['density']); m.k0.copy_(sc['k0']); m.mask_cache.mask.copy_(sc['mask'])
     rk = dict(near=sc['near'], far=sc['far'], bg=1, stepsize=0.5)
+    if args.same_ray:
+        for k in ('rays_o', 'rays_d', 'viewdirs'):
+            sc[k] = sc[k][:1].expand_as(sc[k]).contiguous()
 
     def fwd():
         if args.train:
@@ -47,15 +52,17 @@ for workload in args.workloads.split(','):
         with torch.no_grad():
             return m(sc['rays_o'], sc['rays_d'], sc['viewdirs'], **rk)
 
-    variants = list(itertools.product([int(x) for x in args.density.split(',')], [int(x) for x in args.gather.split(',')]))
+    variants = list(itertools.product([int(x) for x in args.density.split(',')], [int(x) for x in args.gather.split(',')], [int(x) for x in args.experiment.split(',')]))
     ref, times = None, {v: {n: [] for n in NAMES} for v in variants}
     for rep in range(2):
         for v in variants:
-            tune(2, v[0]); tune(3, v[1])
+            tune(2, v[0]); tune(3, v[1]); tune(4, v[2])
             res = fwd()
             torch.cuda.synchronize()
             keys = ('weights', 'raw_alpha', 'alphainv_last', 'ray_id', 'rgb_marched')
-            if ref is None:
+            if v[2]:
+                pass
+            elif ref is None:
                 ref = {k: res[k].detach().clone() for k in keys}
             else:
                 for k in keys:
@@ -69,11 +76,11 @@ for workload in args.workloads.split(','):
     print(f'== {workload}  {"train" if args.train else "inference"} forward   M3 = {ref["weights"].numel()}   (us: avg / min)')
     for v in variants:
         tot = 0.0
-        line = f'  density={v[0]} gather={v[1]}: '
+        line = f'  density={v[0]} gather={v[1]} exp={v[2]}: '
         for n in NAMES:
             xs = times[v][n]
             if xs:
                 line += f'{n[5:]} {sum(xs) / len(xs):6.1f}/{min(xs):6.1f}  '
                 tot += sum(xs) / len(xs)
         print(line + f' | sum {tot:6.1f}')
-    tune(2, 1); tune(3, 1)
+    tune(2, 1); tune(3, 1); tune(4, 0)
