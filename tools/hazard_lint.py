@@ -1,0 +1,249 @@
+"""Static hazard check over gfx950 assembly (`hipcc -S --cuda-device-only`).
+
+Why: hipcc's hazard recogniser pads the wait states gfx940+ needs between certain producer / consumer pairs -- but only for
+instructions it can see.  The body of an `asm` statement is opaque to it: the hand-scheduled transmittance walk of
+csrc/march.hip (chain_walk) first shipped without the one wait state a VALU-written VGPR needs before v_readlane reads it and
+returned the previous step's value.  This script re-derives the distances from the final instruction stream, asm bodies
+included, and fails when a rule is violated, so such a slip is caught on the CPU (tests/test_hazards.py).
+
+Rules (LLVM GCNHazardRecognizer, gfx90a / gfx940 families; wait states = instructions issued in between, `s_nop N` = N + 1):
+  R1  VALU writes a VGPR      -> v_mfma* reads it (A, B or C operand)         >= 2
+  R2  VALU writes a VGPR      -> v_readlane / v_readfirstlane... reads it      >= 1   (v_readlane only)
+  R3  VALU writes an SGPR/VCC -> VALU reads it as a constant                  >= 2
+  R4  VALU writes an SGPR/VCC -> v_readlane / v_writelane lane select         >= 4
+  R5  VALU writes an SGPR     -> VMEM instruction reads it (address)          >= 5
+  R6  VALU writes VCC         -> v_div_fmas                                   >= 4
+Distances are taken over every path (branch targets and fall-through), looking back across loop back-edges.
+
+  python tools/hazard_lint.py file.s [--kernel substr] [--report]      exit status 1 when a rule is violated
+`--report`: also print, per kernel, the histogram of distances from the nearest VALU / ds_read / global_load writer to each
+MFMA operand (what VERDICT r2 asked to compare between a failing and a passing build of shade_bwd_x3).
+"""
+import re
+import sys
+from collections import defaultdict
+
+REG = re.compile(r'\b(v|s|a)(\d+)\b|\b(v|s|a)\[(\d+):(\d+)\]|\b(vcc|exec|m0)(_lo|_hi)?\b')
+
+
+def regs_of(op):
+    out = set()
+    for m in REG.finditer(op):
+        if m.group(1):
+            out.add((m.group(1), int(m.group(2))))
+        elif m.group(3):
+            for i in range(int(m.group(4)), int(m.group(5)) + 1):
+                out.add((m.group(3), i))
+        elif m.group(6):
+            out.add((m.group(6), 0))
+    return out
+
+
+class Ins:
+    __slots__ = ('mn', 'ops', 'dst', 'src', 'ws', 'line', 'text', 'lanesel')
+
+    def __init__(self, mn, ops, line, text):
+        self.mn, self.ops, self.line, self.text = mn, ops, line, text
+        self.ws = 1
+        if mn == 's_nop':
+            try:
+                self.ws = int(ops[0], 0) + 1
+            except (ValueError, IndexError):
+                self.ws = 1
+        self.dst, self.src, self.lanesel = set(), set(), set()
+        if not ops:
+            return
+        n_dst = 1
+        if mn.startswith(('s_cmp', 's_cbranch', 's_branch', 's_waitcnt', 's_nop', 's_barrier', 's_endpgm', 's_setprio', 's_sleep',
+                          's_bitcmp', 's_setreg', 's_sendmsg', 's_trap', 's_dcache', 's_icache')):
+            n_dst = 0
+        if mn.startswith(('global_store', 'buffer_store', 'ds_write', 'flat_store', 'scratch_store', 'global_atomic', 'ds_add',
+                          'ds_cmpst', 'buffer_atomic')) and '_rtn' not in mn and 'rtn' not in mn:
+            n_dst = 0
+        if mn.startswith('v_cmpx'):
+            self.dst.add(('exec', 0))
+            n_dst = 0
+        if mn in ('v_div_scale_f32', 'v_div_scale_f64') or (mn.startswith(('v_add_co', 'v_sub_co', 'v_subrev_co', 'v_addc_co', 'v_subb_co',
+                                                                           'v_mad_u64_u32', 'v_mad_i64_i32')) and len(ops) >= 4):
+            n_dst = 2
+        for o in ops[:n_dst]:
+            self.dst |= regs_of(o)
+        for o in ops[n_dst:]:
+            self.src |= regs_of(o)
+        if mn.startswith('v_cmp') and not mn.startswith('v_cmpx') and mn.endswith('_e32'):      # `v_cmp_*_e32 vcc, a, b`
+            self.dst = {('vcc', 0)}
+            self.src = set().union(*[regs_of(o) for o in ops[1:]]) if len(ops) > 1 else set()
+        if mn.endswith('_e32') and mn.startswith(('v_cndmask', 'v_addc', 'v_subb', 'v_div_fmas')):
+            self.src.add(('vcc', 0))
+        if mn.startswith('v_div_fmas'):
+            self.src.add(('vcc', 0))
+        if mn.startswith(('v_readlane', 'v_writelane')) and len(ops) >= 3:
+            self.lanesel = regs_of(ops[2])
+        if mn.startswith('v_mfma') or mn.startswith('v_smfma'):
+            pass
+        # implicit dst of the multi-dword forms is covered by the range syntax
+
+    def is_valu(self):
+        return self.mn.startswith('v_') and not self.mn.startswith(('v_mfma', 'v_smfma'))
+
+    def is_mfma(self):
+        return self.mn.startswith(('v_mfma', 'v_smfma'))
+
+    def is_vmem(self):
+        return self.mn.startswith(('global_', 'buffer_', 'flat_', 'scratch_'))
+
+
+def parse(path):
+    kernels, cur, name = {}, None, None
+    for ln, raw in enumerate(open(path), 1):
+        line = raw.split(';')[0].rstrip() if not raw.lstrip().startswith(';;#') else ''
+        m = re.match(r'^([A-Za-z_.$][\w.$]*):', raw)
+        if m:
+            lab = m.group(1)
+            if not lab.startswith('.L') and not re.match(r'^\d', lab):
+                name, cur = lab, []
+                kernels[name] = cur
+            elif cur is not None:
+                cur.append(('label', lab))
+            continue
+        m = re.match(r'^(\d+):', raw.strip())
+        if m and cur is not None:
+            cur.append(('label', 'L' + m.group(1) + '@%d' % ln))
+            continue
+        t = line.strip()
+        if not t or t.startswith('.') or cur is None:
+            continue
+        parts = t.split(None, 1)
+        mn = parts[0]
+        if not re.match(r'^(v_|s_|ds_|global_|buffer_|flat_|scratch_)', mn):
+            continue
+        ops = [o.strip() for o in parts[1].split(',')] if len(parts) > 1 else []
+        cur.append(('ins', Ins(mn, ops, ln, t)))
+        if mn == 's_endpgm':
+            pass
+    return kernels
+
+
+def build_cfg(items):
+    """-> instruction list, and for each instruction index the list of predecessor indices."""
+    ins, labels = [], {}
+    for kind, x in items:
+        if kind == 'label':
+            labels.setdefault(x.split('@')[0] if x.startswith('L') and '@' in x else x, []).append(len(ins))
+            if x.startswith('L') and '@' in x:
+                labels.setdefault(x, []).append(len(ins))
+        else:
+            ins.append(x)
+    preds = defaultdict(set)
+    for i, x in enumerate(ins):
+        is_uncond = x.mn in ('s_branch', 's_endpgm', 's_setpc_b64')
+        if not is_uncond and i + 1 < len(ins):
+            preds[i + 1].add(i)
+        if x.mn.startswith(('s_cbranch', 's_branch')) and x.ops:
+            tgt = x.ops[0]
+            m = re.match(r'^(\d+)([bf])$', tgt)
+            cands = []
+            if m:                                   # numeric local label inside an asm statement: nearest in that direction
+                pos = labels.get('L' + m.group(1), [])
+                if m.group(2) == 'b':
+                    cands = [p for p in pos if p <= i][-1:]
+                else:
+                    cands = [p for p in pos if p > i][:1]
+            else:
+                cands = labels.get(tgt, [])
+            for p in cands:
+                if p < len(ins):
+                    preds[p].add(i)
+    return ins, preds
+
+
+def min_dist(ins, preds, i, want, writer_ok, limit):
+    """Minimum wait states between instruction i and the nearest earlier instruction (over all paths) that writes a register
+    in `want` and satisfies writer_ok; None if none within `limit` wait states."""
+    best = None
+    stack = [(p, 0) for p in preds[i]]
+    seen = {}
+    while stack:
+        j, d = stack.pop()
+        if d >= limit or seen.get(j, 1 << 30) <= d:
+            continue
+        seen[j] = d
+        x = ins[j]
+        hit = x.dst & want
+        if hit:
+            if writer_ok(x):
+                best = d if best is None else min(best, d)
+            # any writer of the register ends the search for that register on this path
+            rest = want - hit
+            if not rest:
+                continue
+            for p in preds[j]:
+                stack.append((p, d + x.ws))
+            continue
+        for p in preds[j]:
+            stack.append((p, d + x.ws))
+    return best
+
+
+def check_kernel(name, items, report=False):
+    ins, preds = build_cfg(items)
+    bad = []
+    hist = defaultdict(lambda: defaultdict(int))
+    for i, x in enumerate(ins):
+        def rule(tag, regs, need, ok=lambda w: w.is_valu()):
+            regs = set(regs)
+            if not regs:
+                return
+            d = min_dist(ins, preds, i, regs, ok, need)
+            if d is not None and d < need:
+                bad.append(f'{name}: line {x.line}: {tag}: {d} wait state(s), needs {need}:  {x.text}')
+        v_src = {r for r in x.src if r[0] in ('v', 'a')}
+        s_src = {r for r in x.src if r[0] in ('s', 'vcc')}
+        if x.is_mfma():
+            rule('R1 VALU-written VGPR read by MFMA', v_src, 2)
+            if report:
+                for tag, ok in (('valu', lambda w: w.is_valu()), ('ds_read', lambda w: w.mn.startswith('ds_read')),
+                                ('vmem', lambda w: w.is_vmem())):
+                    d = min_dist(ins, preds, i, v_src, ok, 12)
+                    hist[tag][d if d is not None else '>=12'] += 1
+        if x.mn.startswith('v_readlane'):
+            rule('R2 VALU-written VGPR read by v_readlane', {r for r in regs_of(x.ops[1])} if len(x.ops) > 1 else set(), 1)
+        if x.is_valu() or x.is_mfma():
+            rule('R3 VALU-written SGPR read by VALU', s_src - x.lanesel, 2)
+        if x.lanesel:
+            rule('R4 VALU-written SGPR as lane select', {r for r in x.lanesel if r[0] in ('s', 'vcc')}, 4)
+        if x.is_vmem():
+            rule('R5 VALU-written SGPR read by VMEM', {r for r in x.src if r[0] == 's'}, 5)
+        if x.mn.startswith('v_div_fmas'):
+            rule('R6 VALU-written VCC read by v_div_fmas', {('vcc', 0)}, 4)
+    return bad, hist
+
+
+def main(argv):
+    paths = [a for a in argv if a.endswith('.s')]
+    report = '--report' in argv
+    filt = argv[argv.index('--kernel') + 1] if '--kernel' in argv else None
+    n_bad = 0
+    for p in paths:
+        for name, items in parse(p).items():
+            if filt and filt not in name:
+                continue
+            if not any(k == 'ins' for k, _ in items):
+                continue
+            bad, hist = check_kernel(name, items, report)
+            for b in bad:
+                print('HAZARD', b)
+            n_bad += len(bad)
+            if report:
+                n_ins = sum(1 for k, _ in items if k == 'ins')
+                print(f'{p}: {name[:90]}: {n_ins} instructions')
+                for tag in ('valu', 'ds_read', 'vmem'):
+                    if hist[tag]:
+                        print(f'    nearest {tag:8s} writer of an MFMA operand, wait states -> count: '
+                              + ', '.join(f'{k}:{v}' for k, v in sorted(hist[tag].items(), key=lambda kv: (isinstance(kv[0], str), kv[0]))))
+    print(f'{n_bad} hazard(s)')
+    return 1 if n_bad else 0
+
+
+if __name__ == '__main__':
+    sys.exit(main(sys.argv[1:]))
