@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 SO = os.path.join(CSRC, 'libdvgo_hip.so')
 SOURCES = ['sampling.hip', 'pointwise.hip', 'composite.hip', 'grid_sample.hip', 'march.hip', 'optim.hip', 'shade.hip', 'shade_x3.hip', 'loss.hip', 'brick.hip', 'maintain.hip']
-HEADERS = ['common.h', os.path.join('..', '..', 'include', 'dvgo_hip.h')]
+HEADERS = ['common.h', 'scan.h', os.path.join('..', '..', 'include', 'dvgo_hip.h')]
 
 # -ffp-contract=off : a*b+c is fused only where the source says fmaf(), so that index and
 #                     position arithmetic is bit-identical to the CPU oracle

@@ -19,118 +19,13 @@
 //           parameters: the gradient then never exists in HBM.
 #include "common.h"
 
-// Exclusive scan of n values by ONE workgroup of 1024 threads, 8192 values per pass (one pass for a training batch's rays
-// and for the bricks of a 160^3 grid): every thread loads its 8 values of the pass up front (coalesced: value r * 1024 +
-// tid), the 8 rows are scanned per wave with shuffles, the 8 x 16 wave totals by wave 0 through LDS, and each value is
-// handed its exclusive prefix (and itself).  One memory round trip and two barriers per pass.  Values are 64-bit so that
-// several running sums can ride in one scan.  Returns the total.
-template <typename Load, typename Store>
-__device__ __forceinline__ unsigned long long block_scan_u64(int n, Load load, Store store) {
-  constexpr int R = 8;
-  __shared__ unsigned long long s_part[R * 16];
-  __shared__ unsigned long long s_total;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  unsigned long long carry = 0ull;
-  for (int base = 0; base < n; base += R * 1024) {
-    unsigned long long v[R], inc[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int i = base + r * 1024 + tid;
-      v[r] = (i < n) ? load(i) : 0ull;
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r) inc[r] = v[r];
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const unsigned long long o = __shfl_up(inc[r], d);
-        if (lane >= d) inc[r] += o;
-      }
-    }
-    if (lane == 63) {
-#pragma unroll
-      for (int r = 0; r < R; ++r) s_part[r * 16 + wave] = inc[r];
-    }
-    __syncthreads();
-    if (wave == 0) {                               // the 128 wave totals, in value order: two per lane
-      const unsigned long long p0 = s_part[2 * lane], p1 = s_part[2 * lane + 1];
-      unsigned long long t = p0 + p1;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const unsigned long long o = __shfl_up(t, d);
-        if (lane >= d) t += o;
-      }
-      s_part[2 * lane] = t - p0 - p1;
-      s_part[2 * lane + 1] = t - p1;
-      if (lane == 63) s_total = t;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int i = base + r * 1024 + tid;
-      if (i < n) store(i, carry + s_part[r * 16 + wave] + inc[r] - v[r], v[r]);
-    }
-    carry += s_total;
-    __syncthreads();
-  }
-  return carry;
-}
-
-// exclusive scan of n int32 counts: out[i] = sum of cnt[0..i), out[n] = total
-template <typename OutT>
-__device__ __forceinline__ void block_scan_i32(const int32_t* __restrict__ cnt, int n, OutT* __restrict__ out) {
-  const unsigned long long total = block_scan_u64(
-      n, [&](int i) { return (unsigned long long)cnt[i]; }, [&](int i, unsigned long long ex, unsigned long long) { out[i] = (OutT)ex; });
-  if (threadIdx.x == 0) out[n] = (OutT)total;
-}
-
-// Heavy bricks (a thin surface crossed by every ray: tens of thousands of entries where the median brick has hundreds)
-// are cut into SLICES of `slice_len` entries.  Slice 0 is the brick's own work item; the further slices are EXTRA work
-// items appended after the bricks, and the slices of a brick meet in scratch tiles (see brick_accumulate_kernel).
-// This scan turns the per-brick counts into
-//   off      [nb + 1]  first entry of each brick's list (and `cursor`, the fill cursors)
-//   extra    [nb + 1]  first extra work item of each brick (ceil(cnt / slice_len) - 1 of them, none for most)
-//   active   [nb + 1]  the non-empty bricks, in brick order; active[nb] = their number (a sparse scene touches a tenth
-//                      of the bricks: the workgroups beyond that number leave after one load)
-//   extra_brick [<= n_extra_max]  the brick of every extra work item
-// and clears the counters, which then serve as the arrival counters of the slices.
-#define DVGO_BRICK_SLICE_DEFAULT 1024   // entries per work item
-
-__device__ __forceinline__ void brick_tables(int32_t* __restrict__ cnt, int nb, int32_t* __restrict__ off,
-                                             int32_t* __restrict__ cursor, int32_t* __restrict__ extra, int32_t* __restrict__ active,
-                                             int32_t* __restrict__ extra_brick, int n_extra_max, int slice_len) {
-  // the three running sums in one 64-bit scan: entries (28 bits) | extra items (18) | non-empty bricks (18)
-  auto slices = [&](int c) { return c > slice_len ? (c + slice_len - 1) / slice_len : 1; };
-  const unsigned long long total = block_scan_u64(
-      nb,
-      [&](int i) {
-        const int c = cnt[i];
-        if (!extra) return (unsigned long long)c;
-        return (unsigned long long)c | ((unsigned long long)(slices(c) - 1) << 28) | ((unsigned long long)(c > 0) << 46);
-      },
-      [&](int i, unsigned long long ex, unsigned long long v) {
-        const int e0 = extra ? (int)(ex & 0xfffffffull) : (int)ex;
-        off[i] = e0; cursor[i] = e0;
-        if (extra) {
-          const int e1 = (int)((ex >> 28) & 0x3ffffull), n_extra = (int)((v >> 28) & 0x3ffffull);
-          extra[i] = e1; cnt[i] = 0;
-          if (v >> 46) active[(int)(ex >> 46)] = i;
-          for (int k = 0; k < n_extra; ++k)
-            if (e1 + k < n_extra_max) extra_brick[e1 + k] = i;
-        }
-      });
-  if (threadIdx.x == 0) {
-    off[nb] = extra ? (int)(total & 0xfffffffull) : (int)total;
-    if (extra) { extra[nb] = (int)((total >> 28) & 0x3ffffull); active[nb] = (int)(total >> 46); }
-  }
-}
+#include "scan.h"
 
 __global__ void __launch_bounds__(1024)
 brick_scan_kernel(int32_t* __restrict__ cnt, int nb, int32_t* __restrict__ off, int32_t* __restrict__ cursor,
                   int32_t* __restrict__ extra, int32_t* __restrict__ active, int32_t* __restrict__ extra_brick, int n_extra_max,
                   int slice_len) {
-  brick_tables(cnt, nb, off, cursor, extra, active, extra_brick, n_extra_max, slice_len);
+  brick_tables<16, false>(cnt, nb, off, cursor, extra, active, extra_brick, n_extra_max, slice_len);
 }
 
 // the two scans between march_density and march_gather in one launch: workgroup 0 the kept-sample counts of the rays
@@ -140,8 +35,8 @@ march_scans_kernel(const int32_t* __restrict__ n3, int n_rays, int64_t* __restri
                    int32_t* __restrict__ brick_cnt, int nb, int32_t* __restrict__ brick_off,
                    int32_t* __restrict__ brick_cursor, int32_t* __restrict__ extra, int32_t* __restrict__ active,
                    int32_t* __restrict__ extra_brick, int n_extra_max, int slice_len) {
-  if (blockIdx.x == 0) block_scan_i32<int64_t>(n3, n_rays, off3);
-  else brick_tables(brick_cnt, nb, brick_off, brick_cursor, extra, active, extra_brick, n_extra_max, slice_len);
+  if (blockIdx.x == 0) block_scan_i32<16, int64_t>(n_rays, off3, [&](int i) { return n3[i]; });
+  else brick_tables<16, false>(brick_cnt, nb, brick_off, brick_cursor, extra, active, extra_brick, n_extra_max, slice_len);
 }
 
 struct BrickAdam {

@@ -18,6 +18,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "scan.h"
 
 __device__ __forceinline__ unsigned long long lanemask_lt(int lane) {
   return (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -147,6 +148,15 @@ __device__ __forceinline__ void brick_emit(bool act, int i0, int j0, int k0, int
   }
 }
 
+// What the LAST workgroup of march_density to finish does with everybody's per-ray counts (ticket == NULL: nothing; the
+// caller then launches dvgo_march_scans): off3 = exclusive scan of n3, and for training the brick tables of csrc/scan.h.
+struct MarchTail {
+  int32_t* ticket;            // one zero-initialised int32, left at zero again
+  int64_t* off3;
+  int32_t *brick_off, *brick_cursor, *extra, *active, *extra_brick;
+  int nb, n_extra_max, slice_len;
+};
+
 // ----------------------------------------------------------------------------------
 // The transmittance walk of one 64-step chunk (K12, render_utils_kernel.cu:448-454), hand-scheduled: hipcc's version of
 // the same loop spends 8 vector + 11 scalar instructions per kept sample -- the carry bounces between a VGPR and an SGPR,
@@ -208,10 +218,12 @@ march_density_kernel(float* __restrict__ rays_start, float* __restrict__ rays_di
                      dvgo_rec2_t* __restrict__ rec2,
                      int32_t* __restrict__ n2, int32_t* __restrict__ n3,
                      float* __restrict__ alphainv_last, int32_t* __restrict__ brick_cnt,
-                     const float* __restrict__ rays_o, const float* __restrict__ rays_d, float near, float far) {
-  const int64_t ray = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+                     const float* __restrict__ rays_o, const float* __restrict__ rays_d, float near, float far, MarchTail tail) {
+  const int64_t ray_raw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
-  if (ray >= n_rays) return;
+  const bool live = ray_raw < n_rays;           // (the waves past the last ray of the last workgroup still join its barriers)
+  const int64_t ray = live ? ray_raw : n_rays - 1;
+  if (!live && tail.ticket == nullptr) return;
   int ns;
   float sx, sy, sz, dx, dy, dz;
   if (rays_o != nullptr) {
@@ -221,7 +233,7 @@ march_density_kernel(float* __restrict__ rays_start, float* __restrict__ rays_di
                                       rays_d[3 * ray + 2], P.mnx, P.mny, P.mnz, P.mxx, P.mxy, P.mxz, near, far, P.stepdist);
     sx = R.sx; sy = R.sy; sz = R.sz; dx = R.dx; dy = R.dy; dz = R.dz;
     ns = __builtin_amdgcn_readfirstlane((int)R.n);
-    if (lane == 0) {
+    if (lane == 0 && live) {
       n_steps[ray] = R.n;
       rays_start[3 * ray] = sx; rays_start[3 * ray + 1] = sy; rays_start[3 * ray + 2] = sz;
       rays_dir[3 * ray] = dx; rays_dir[3 * ray + 1] = dy; rays_dir[3 * ray + 2] = dz;
@@ -232,6 +244,7 @@ march_density_kernel(float* __restrict__ rays_start, float* __restrict__ rays_di
     dx = rays_dir[3 * ray]; dy = rays_dir[3 * ray + 1]; dz = rays_dir[3 * ray + 2];
   }
   const int64_t cs0 = (rays_o != nullptr) ? ray * rec_stride : rec_base(cum, n_steps, rec_stride, ray);
+  if (!live) ns = 0;
   const int64_t YZ = (int64_t)P.Y * P.Z;
   const bool filt = P.thres > 0.0f;
   const bool pairs = FAST && P.Z >= 2;
@@ -342,11 +355,29 @@ march_density_kernel(float* __restrict__ rays_start, float* __restrict__ rays_di
     if (brick_cnt != nullptr) brick_emit<false>(valid2, t.i0, t.j0, t.k0, P.X, P.Y, P.Z, lane, brick_cnt, nullptr, make_int4(0, 0, 0, 0));
     if (stop) break;
   }
-  if (lane == 0) {
+  if (lane == 0 && live) {
     n2[ray] = c2;
-    n3[ray] = c3;
     alphainv_last[ray] = Tc;
+    // n3 is what the tail reads back on another CU: a write-through (sc1) store, drained before the ticket below
+    if (tail.ticket != nullptr) __hip_atomic_store(&n3[ray], c3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else n3[ray] = c3;
   }
+  if (tail.ticket == nullptr) return;
+  // ---- tail: the last workgroup to finish turns the counts into offsets / brick tables (cdna_hip_programming.md Guideline 16
+  // R1: every storing wave drains its sc1 stores and its brick-count atomics, one lane takes an agent-scope ticket behind the
+  // workgroup's barrier, the consumer reads with sc1 loads only)
+  __shared__ int s_is_last;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0)
+    s_is_last = __hip_atomic_fetch_add(tail.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+  __syncthreads();
+  if (!s_is_last) return;
+  block_scan_i32_sc1<DVGO_BLOCK / 64, int64_t>(n3, (int)n_rays, tail.off3);
+  if (brick_cnt != nullptr && tail.brick_off != nullptr)
+    brick_tables<DVGO_BLOCK / 64, true>(brick_cnt, tail.nb, tail.brick_off, tail.brick_cursor, tail.extra, tail.active,
+                                        tail.extra_brick, tail.n_extra_max, tail.slice_len);
+  if (threadIdx.x == 0) __hip_atomic_store(tail.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ----------------------------------------------------------------------------------
@@ -945,7 +976,8 @@ int dvgo_march_density(float* rays_start, float* rays_dir, int64_t* n_steps,
                        int X, int Y, int Z, float act_shift, float interval, float fast_color_thres,
                        dvgo_rec2_t* rec2, int32_t* n2, int32_t* n3,
                        float* alphainv_last, int32_t* brick_cnt, const float* rays_o, const float* rays_d, float near,
-                       float far, void* stream) {
+                       float far, int32_t* tail_ticket, int64_t* off3, int n_bricks, int32_t* brick_off, int32_t* brick_cursor,
+                       int32_t* extra_off, int32_t* active, int32_t* extra_brick, int n_extra_max, int slice_len, void* stream) {
   if (n_rays < 0 || X <= 0 || Y <= 0 || Z <= 0) return DVGO_EINVAL;
   if (n_rays == 0) return 0;
   if (!rays_start || !rays_dir || !n_steps || !xyz_min || !xyz_max || !density ||
@@ -957,14 +989,24 @@ int dvgo_march_density(float* rays_start, float* rays_dir, int64_t* n_steps,
   if (!dvgo_fits(n_rays * 64)) return DVGO_ERANGE;
   const MarchParams P = make_params(xyz_min, xyz_max, stepdist, xyz2ijk_scale, xyz2ijk_shift, mX, mY, mZ,
                                     X, Y, Z, act_shift, interval, fast_color_thres);
+  MarchTail tail;
+  tail.ticket = tail_ticket; tail.off3 = off3;
+  tail.brick_off = brick_off; tail.brick_cursor = brick_cursor; tail.extra = extra_off; tail.active = active;
+  tail.extra_brick = extra_brick; tail.nb = n_bricks; tail.n_extra_max = n_extra_max; tail.slice_len = slice_len;
+  if (tail_ticket) {
+    if (!off3 || n_rays >= ((int64_t)1 << 31)) return DVGO_EINVAL;
+    if (brick_cnt && brick_off && (!brick_cursor || n_bricks <= 0)) return DVGO_EINVAL;
+    if (brick_cnt && brick_off && extra_off && (!active || !extra_brick || n_extra_max < 0 || slice_len < 256 || n_bricks >= (1 << 18)))
+      return DVGO_EINVAL;
+  }
   if (g_tuning[DVGO_TUNE_DENSITY_FWD])
     march_density_kernel<true><<<dvgo_blocks(n_rays * 64, DVGO_BLOCK), DVGO_BLOCK, 0, (hipStream_t)stream>>>(
         rays_start, rays_dir, n_steps, n_steps_cumsum, rec_stride, n_rays, mask, density, P, rec2, n2, n3,
-        alphainv_last, brick_cnt, rays_o, rays_d, near, far);
+        alphainv_last, brick_cnt, rays_o, rays_d, near, far, tail);
   else
     march_density_kernel<false><<<dvgo_blocks(n_rays * 64, DVGO_BLOCK), DVGO_BLOCK, 0, (hipStream_t)stream>>>(
         rays_start, rays_dir, n_steps, n_steps_cumsum, rec_stride, n_rays, mask, density, P, rec2, n2, n3,
-        alphainv_last, brick_cnt, rays_o, rays_d, near, far);
+        alphainv_last, brick_cnt, rays_o, rays_d, near, far, tail);
   DVGO_LAUNCH_CHECK();
   return 0;
 }

@@ -64,6 +64,21 @@ def _rec_stride(cfg, n_rays):
 # Owner-computes gradient scatter (csrc/brick.hip): samples are listed per 8x8x8 brick, one workgroup sums a brick;
 # no float atomics, no zero-fill.  The default whenever both grids want a gradient, share the lattice and the
 # feature grid is channels-last with a built channel count; the atomic scatters below remain as A/B variants.
+# The scans between march_density and march_gather (per-ray offsets, brick tables) done by march_density's last workgroup
+# instead of a launch of their own (False: dvgo_march_scans, A/B and tests)
+TAIL_SCANS = False        # (with 256-thread workgroups the tail is 8 serial passes: +30 us; pays with the 16-ray kernel)
+_TICKETS = {}
+
+
+def _tail_ticket(dev, st):
+    """The ticket word of the tail: one zeroed int32 per (device, stream); the kernel leaves it at zero."""
+    key = (dev.index, int(st.value or 0))
+    t = _TICKETS.get(key)
+    if t is None:
+        t = _TICKETS[key] = torch.zeros(1, dtype=torch.int32, device=dev)
+    return t
+
+
 BRICK_SLICE = None          # entries per work item of the brick kernel (None: the library's default)
 BRICK_SCATTER = True
 BRICK_CHANNELS = (3, 4, 9, 12)
@@ -170,14 +185,21 @@ class _FusedMarch(torch.autograd.Function):
                     extra_brick = torch.empty(max(n_extra_max, 1), dtype=torch.int32, device=dev)
             mask = cfg.mask
             mshape = mask.shape if mask is not None else (0, 0, 0)
+            tail = TAIL_SCANS and 0 < N <= 16384          # the scans ride on march_density's last workgroup
             L.call('dvgo_march_density', ptr(start), ptr(dirs), ptr(n_steps), ptr(cum), _i64(stride), _i64(N),
                    cfg.xyz_min_h, cfg.xyz_max_h, _flt(cfg.stepdist), ptr(mask), _int(mshape[0]), _int(mshape[1]),
                    _int(mshape[2]), cfg.scale_h, cfg.shift_h, ptr(density), _int(X), _int(Y), _int(Z),
                    _flt(cfg.act_shift), _flt(cfg.interval), _flt(cfg.thres), ptr(rec2), ptr(n2), ptr(n3),
                    ptr(last), ptr(brick_cnt), ptr(rays_o if setup_in_march else None), ptr(rays_d if setup_in_march else None),
-                   _flt(cfg.near), _flt(cfg.far), st)
+                   _flt(cfg.near), _flt(cfg.far), ptr(_tail_ticket(dev, st) if tail else None), ptr(off3),
+                   _int(nb if bricks else 0), ptr(brick_off[0] if bricks else None), ptr(brick_cur),
+                   ptr(brick_off[1] if extra_brick is not None else None),
+                   ptr(brick_off[2] if extra_brick is not None else None), ptr(extra_brick), _int(n_extra_max),
+                   _int(slice_len), st)
             n_entries = 0
-            if N <= 16384:              # both scans in one launch (one workgroup each)
+            if tail:
+                pass                    # the last workgroup of march_density has written off3 and the brick tables
+            elif N <= 16384:            # both scans in one launch (one workgroup each)
                 L.call('dvgo_march_scans', ptr(n3), _i64(N), ptr(off3), ptr(brick_cnt), _int(nb if bricks else 0),
                        ptr(brick_off[0] if bricks else None), ptr(brick_cur),
                        ptr(brick_off[1] if extra_brick is not None else None),

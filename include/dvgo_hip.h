@@ -212,6 +212,13 @@ int dvgo_march_density(float* rays_start, float* rays_dir,
                                           /* rays_o != NULL (fixed-stride records, stepdist > 0): K1-K3 of
                                              dvgo_sample_pts_prepare are computed by this launch and rays_start / rays_dir /
                                              n_steps are OUTPUTS; NULL: they are inputs */,
+                       int32_t* tail_ticket /* NULL, or one zero-initialised int32 (left at zero): the LAST workgroup to finish
+                                               also does the work of dvgo_march_scans -- off3 [n_rays + 1] = exclusive scan of
+                                               n3 and, when brick_cnt and brick_off are given, the brick tables -- so that no
+                                               scan launch is needed between this call and dvgo_march_gather.  One call at a
+                                               time per ticket word. */,
+                       int64_t* off3, int n_bricks, int32_t* brick_off, int32_t* brick_cursor, int32_t* extra_off,
+                       int32_t* active, int32_t* extra_brick, int n_extra_max, int slice_len,
                        void* stream);
 
 /* dvgo_march_hit: hit[r] = 1 iff ray r has an in-box sample whose nearest occupancy voxel is set -- the fused
