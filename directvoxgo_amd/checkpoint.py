@@ -53,7 +53,15 @@ def _portable_optimizer_state(optimizer):
 
 
 def save_checkpoint(path, model, optimizer, global_step):
-    """run.py:420-437"""
+    """run.py:420-437.  Data-parallel runs with the sharded grid update (train.TrainStep): every rank holds current Adam
+    moments for its own X-slab only, so the slabs are all-gathered here first -- a collective: call this on EVERY rank
+    (`path=None` on the ranks that do not write).  The file then holds the complete state a single process would have
+    written, as the reference's format implies."""
+    ts = getattr(optimizer, '_dvgo_sharded_by', None)
+    if ts is not None and getattr(ts, '_moments_sharded', False):
+        ts.gather_optimizer_state()
+    if path is None:
+        return
     torch.save({'global_step': global_step, 'model_kwargs': model.get_kwargs(),
                 'model_state_dict': _portable_state_dict(model),
                 'optimizer_state_dict': _portable_optimizer_state(optimizer) if optimizer is not None else None}, path)

@@ -59,15 +59,21 @@ __device__ __forceinline__ void adam4(float4& p, const float4 g, float4& m, floa
   adam_one<MODE>(p.w, g.w, m.w, v.w, 0.f, ss, b1, b2, eps);
 }
 
-// ADAM: 0 = write the dense gradients, 1 = apply the (masked) Adam update in place
-template <int C, int ADAM>
+// MODE: 0 = write the dense gradients, 1 = apply the (masked) Adam update in place,
+//       2 = data parallel, first half: the brick's finished 512 x TS tile goes to tiles[index of the brick in `active`]
+//           (`active` = the bricks ANY rank touched; a brick this rank has no entry for writes zeros) -- the tiles are then
+//           summed over the ranks by one all-reduce of a compact buffer,
+//       3 = data parallel, second half: no list is read; the tile comes from tiles[index] and the masked Adam update of the
+//           brick is applied from it (every rank applies the same update: parameters and moments stay replicated).
+template <int C, int MODE>
 __global__ void __launch_bounds__(256, 4)          // 4 workgroups per CU (LDS allows exactly 4): at most 128 VGPRs
 brick_accumulate_kernel(const int32_t* __restrict__ off, const int32_t* __restrict__ extra_off,
                         const int32_t* __restrict__ active, const int32_t* __restrict__ extra_brick,
                         int32_t* __restrict__ arrive, float* __restrict__ scratch,
                         const int4* __restrict__ recs, const float* __restrict__ rays_start, const float* __restrict__ rays_dir,
                         const float* __restrict__ g_feat, BrickGeom G, float* __restrict__ grad_k0,
-                        float* __restrict__ grad_density, BrickAdam A) {
+                        float* __restrict__ grad_density, BrickAdam A, float* __restrict__ tiles) {
+  constexpr bool ADAM = MODE == 1 || MODE == 3;
   constexpr int CE = C + 1;                      // the density gradient rides as channel C
   constexpr int G4 = ((CE + 3) / 4) | 1;         // staged gradient rows: an ODD number of 16-byte pieces, so that the
   constexpr int GS = 4 * G4;                     //   ds_read_b128 of 16 lanes with different rows spread over the banks
@@ -92,19 +98,21 @@ brick_accumulate_kernel(const int32_t* __restrict__ off, const int32_t* __restri
   // walk the `active` list instead (the dense-gradient form must also write the zeros of the others).  The blocks behind
   // the bricks are the extra slices of heavy bricks.
   const int nb8 = (G.nb + 7) & ~7;
-  int b, slice = 0;
+  int b, slice = 0, tile_idx = 0;
   if ((int)blockIdx.x < nb8) {
-    if (ADAM && active != nullptr) {
+    if ((ADAM || MODE == 2) && active != nullptr) {
       const int n_active = active[G.nb];
       const int per = (n_active + 7) >> 3, r = (int)(blockIdx.x >> 3);
       const int idx = (int)(blockIdx.x & 7) * per + r;
       if (r >= per || idx >= n_active) return;
       b = active[idx];
+      tile_idx = idx;
     } else {
       b = (int)(blockIdx.x & 7) * (nb8 >> 3) + (int)(blockIdx.x >> 3);
       if (b >= G.nb) return;
     }
   } else {
+    if (MODE == 3) return;                       // (tiles in: one work item per brick)
     const int x = (int)blockIdx.x - nb8;
     if (x >= extra_off[G.nb]) return;
     b = extra_brick[x];
@@ -112,8 +120,8 @@ brick_accumulate_kernel(const int32_t* __restrict__ off, const int32_t* __restri
   }
   const int bz = b % G.BZ, by = (b / G.BZ) % G.BY, bx = b / (G.BZ * G.BY);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n_b = off[b + 1] - off[b];
-  if (ADAM && n_b == 0) return;                  // untouched brick: nothing to update
+  const int n_b = (MODE == 3) ? 0 : off[b + 1] - off[b];
+  if (MODE == 1 && n_b == 0) return;             // untouched brick: nothing to update
   const int n_slices = (extra_off != nullptr && n_b > G.slice_len) ? (n_b + G.slice_len - 1) / G.slice_len : 1;
   const int lo = off[b] + slice * G.slice_len;
   const int n = n_slices > 1 ? min(G.slice_len, n_b - slice * G.slice_len) : n_b;
@@ -248,10 +256,16 @@ brick_accumulate_kernel(const int32_t* __restrict__ off, const int32_t* __restri
   }
 
   // the finished tile, voxel-major, through LDS so that the global accesses below are coalesced
+  if (MODE == 3) {
+    const float4* src = reinterpret_cast<const float4*>(tiles + (int64_t)tile_idx * (512 * TS));
+    float4* dst = reinterpret_cast<float4*>(&u.tile[0][0]);
+    for (int q = tid; q < 512 * TS / 4; q += 256) dst[q] = src[q];
+  } else {
 #pragma unroll
-  for (int c = 0; c < TS; ++c) {
-    u.tile[2 * tid][c] = (c < CE) ? acc0[c] : 0.f;
-    u.tile[2 * tid + 1][c] = (c < CE) ? acc1[c] : 0.f;
+    for (int c = 0; c < TS; ++c) {
+      u.tile[2 * tid][c] = (c < CE) ? acc0[c] : 0.f;
+      u.tile[2 * tid + 1][c] = (c < CE) ? acc1[c] : 0.f;
+    }
   }
   __syncthreads();
 
@@ -290,6 +304,20 @@ brick_accumulate_kernel(const int32_t* __restrict__ off, const int32_t* __restri
     __syncthreads();
   }
 
+  if (MODE == 2) {
+    // the tile leaves as it stands (padding lanes included: the all-reduce sums whole tiles).  The slices of a heavy brick
+    // arrive here through the last one; its `tile_idx` is the brick's place in `active`, found by binary search (the list
+    // is in brick order) when this work item is an extra slice
+    if (slice > 0) {
+      int lo_i = 0, hi_i = active[G.nb] - 1;
+      while (lo_i < hi_i) { const int mid = (lo_i + hi_i) >> 1; if (active[mid] < b) lo_i = mid + 1; else hi_i = mid; }
+      tile_idx = lo_i;
+    }
+    float4* dst = reinterpret_cast<float4*>(tiles + (int64_t)tile_idx * (512 * TS));
+    const float4* src = reinterpret_cast<const float4*>(&u.tile[0][0]);
+    for (int q = tid; q < 512 * TS / 4; q += 256) dst[q] = src[q];
+    return;
+  }
   const int x0 = bx << DVGO_BRICK_LOG, y0 = by << DVGO_BRICK_LOG, z0 = bz << DVGO_BRICK_LOG;
   if constexpr (C == 12) {
     // 4 lanes per voxel: three float4 of features + the density scalar; 8 voxels in z = 384 contiguous bytes of k0.
@@ -415,14 +443,20 @@ int dvgo_brick_accumulate(const int32_t* brick_off, const int32_t* extra_off, co
                           int C, int X, int Y, int Z, float* grad_k0, float* grad_density,
                           float* p_k0, float* m_k0, float* v_k0, float step_size_k0, int masked_k0,
                           float* p_density, float* m_density, float* v_density, float step_size_density,
-                          int masked_density, float beta1, float beta2, float eps, const float* step_sizes_dev, void* stream) {
+                          int masked_density, float beta1, float beta2, float eps, const float* step_sizes_dev,
+                          float* tiles, int tiles_mode, void* stream) {
   const int nb = dvgo_n_bricks(X, Y, Z);
   if (nb < 0) return nb;
   const bool adam = p_k0 != nullptr;
-  if (!brick_off || !recs || !rays_start || !rays_dir || !xyz_min || !xyz_max) return DVGO_EINVAL;
+  if (tiles_mode != 0 && tiles_mode != 2 && tiles_mode != 3) return DVGO_EINVAL;
+  if (tiles_mode && (!tiles || !active)) return DVGO_EINVAL;
+  if (tiles_mode == 3 && !adam) return DVGO_EINVAL;
+  if (tiles_mode == 3) {                         // tiles in: no lists are read
+    if (!xyz_min || !xyz_max) return DVGO_EINVAL;
+  } else if (!brick_off || !recs || !rays_start || !rays_dir || !xyz_min || !xyz_max) return DVGO_EINVAL;
   if (extra_off && (!active || !extra_brick || !arrive || !scratch || n_extra_max < 0 || slice_len < 256)) return DVGO_EINVAL;
   if (adam && (!m_k0 || !v_k0 || !p_density || !m_density || !v_density)) return DVGO_EINVAL;
-  if (!adam && (!grad_k0 || !grad_density)) return DVGO_EINVAL;
+  if (!adam && !tiles_mode && (!grad_k0 || !grad_density)) return DVGO_EINVAL;
   if (C == 12 && ((((uintptr_t)grad_feat | (uintptr_t)grad_k0 | (uintptr_t)p_k0 | (uintptr_t)m_k0 | (uintptr_t)v_k0) & 15) != 0))
     return DVGO_EINVAL;
   BrickGeom G;
@@ -437,18 +471,20 @@ int dvgo_brick_accumulate(const int32_t* brick_off, const int32_t* extra_off, co
   A.ss_k = step_size_k0; A.ss_d = step_size_density; A.beta1 = beta1; A.beta2 = beta2; A.eps = eps;
   A.ss_dev = step_sizes_dev;
   A.masked_k = masked_k0; A.masked_d = masked_density;
-  const int64_t items = ((nb + 7) & ~7) + (extra_off ? n_extra_max : 0);     // bricks (padded to the 8 XCDs), then extra slices
+  const int64_t items = ((nb + 7) & ~7) + ((extra_off && tiles_mode != 3) ? n_extra_max : 0);     // bricks (padded to the 8 XCDs), then extra slices
   if (items >= ((int64_t)1 << 30)) return DVGO_ERANGE;
   const int blocks = (int)items;
   hipStream_t s = (hipStream_t)stream;
-#define DVGO_BRICK_ACC(CC)                                                                                        \
-  do {                                                                                                            \
-    if (adam) brick_accumulate_kernel<CC, 1><<<blocks, 256, 0, s>>>(brick_off, extra_off, active, extra_brick, arrive, scratch, \
-                                                                     (const int4*)recs, rays_start, rays_dir,             \
-                                                                     grad_feat, G, grad_k0, grad_density, A);             \
-    else brick_accumulate_kernel<CC, 0><<<blocks, 256, 0, s>>>(brick_off, extra_off, active, extra_brick, arrive, scratch,   \
-                                                                (const int4*)recs, rays_start, rays_dir,                  \
-                                                                grad_feat, G, grad_k0, grad_density, A);                  \
+#define DVGO_BRICK_LAUNCH(CC, MD)                                                                                  \
+  brick_accumulate_kernel<CC, MD><<<blocks, 256, 0, s>>>(brick_off, extra_off, active, extra_brick, arrive, scratch,  \
+                                                          (const int4*)recs, rays_start, rays_dir, grad_feat, G, grad_k0, \
+                                                          grad_density, A, tiles)
+#define DVGO_BRICK_ACC(CC)                                  \
+  do {                                                      \
+    if (tiles_mode == 2) DVGO_BRICK_LAUNCH(CC, 2);          \
+    else if (tiles_mode == 3) DVGO_BRICK_LAUNCH(CC, 3);     \
+    else if (adam) DVGO_BRICK_LAUNCH(CC, 1);                \
+    else DVGO_BRICK_LAUNCH(CC, 0);                          \
   } while (0)
   if (C == 12) DVGO_BRICK_ACC(12);
   else if (C == 9) DVGO_BRICK_ACC(9);
@@ -456,6 +492,7 @@ int dvgo_brick_accumulate(const int32_t* brick_off, const int32_t* extra_off, co
   else if (C == 4) DVGO_BRICK_ACC(4);
   else return DVGO_ERANGE;
 #undef DVGO_BRICK_ACC
+#undef DVGO_BRICK_LAUNCH
   DVGO_LAUNCH_CHECK();
   return 0;
 }

@@ -106,7 +106,81 @@ maskout_near_cam_kernel(float* __restrict__ density, const float* __restrict__ g
   if (best <= near) density[v] = value;
 }
 
+// ----------------------------------------------------------------------------------
+// rays_of_view: rays_o / rays_d / viewdirs of the pixels [p0, p0 + n) of one view, row-major (lib/ray_utils.py:9-85:
+// get_rays + the viewdirs of get_rays_of_a_view + ndc_rays), one thread per pixel -- instead of ~10 framework launches and
+// 23 MB of intermediate [H, W, 3] tensors per 800 x 800 view in front of a 12 ms render.  The arithmetic is the
+// reference's, operation for operation in fp32 without contraction: pixel coordinate (+ 0.5 for mode 'center'), flips,
+// dirs = ((i - cx) / fx, -(j - cy) / fy, -1) (inverse_y: (.., (j - cy) / fy, 1)), rays_d[k] = sum_m dirs[m] * c2w[k][m]
+// (three products, summed left to right), rays_o = c2w[:3, 3], viewdirs = rays_d / |rays_d|.
+// ----------------------------------------------------------------------------------
+struct ViewCam {
+  float R[3][3], t[3];
+  float fx, fy, cx, cy;
+  int H, W;
+  int inverse_y, flip_x, flip_y, center, ndc;
+  float ndc_focal, ndc_near;
+};
+
+__global__ void __launch_bounds__(DVGO_BLOCK)
+rays_of_view_kernel(ViewCam V, int64_t p0, int64_t n, float* __restrict__ rays_o, float* __restrict__ rays_d,
+                    float* __restrict__ viewdirs) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  const int64_t p = p0 + q;
+  int row = (int)(p / V.W), col = (int)(p - (int64_t)row * V.W);
+  if (V.flip_x) col = V.W - 1 - col;
+  if (V.flip_y) row = V.H - 1 - row;
+  const float i = (float)col + (V.center ? 0.5f : 0.0f), j = (float)row + (V.center ? 0.5f : 0.0f);
+  float d0 = (i - V.cx) / V.fx, d1, d2;
+  if (V.inverse_y) { d1 = (j - V.cy) / V.fy; d2 = 1.0f; }
+  else { d1 = -(j - V.cy) / V.fy; d2 = -1.0f; }
+  float rd[3], ro[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    rd[k] = (d0 * V.R[k][0] + d1 * V.R[k][1]) + d2 * V.R[k][2];
+    ro[k] = V.t[k];
+  }
+  const float nrm = sqrtf((rd[0] * rd[0] + rd[1] * rd[1]) + rd[2] * rd[2]);
+  if (viewdirs != nullptr) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) viewdirs[3 * q + k] = rd[k] / nrm;
+  }
+  if (V.ndc) {                                  // lib/ray_utils.py:60-77
+    const float near = V.ndc_near, f = V.ndc_focal;
+    const float t = -(near + ro[2]) / rd[2];
+    const float ox = ro[0] + t * rd[0], oy = ro[1] + t * rd[1], oz = ro[2] + t * rd[2];
+    const float sw = -1.0f / ((float)V.W / (2.0f * f)), sh = -1.0f / ((float)V.H / (2.0f * f));
+    const float o0 = sw * ox / oz, o1 = sh * oy / oz, o2 = 1.0f + 2.0f * near / oz;
+    const float e0 = sw * (rd[0] / rd[2] - ox / oz), e1 = sh * (rd[1] / rd[2] - oy / oz), e2 = -2.0f * near / oz;
+    ro[0] = o0; ro[1] = o1; ro[2] = o2; rd[0] = e0; rd[1] = e1; rd[2] = e2;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { rays_o[3 * q + k] = ro[k]; rays_d[3 * q + k] = rd[k]; }
+}
+
 extern "C" {
+
+int dvgo_rays_of_view(int H, int W, const float* K4 /* host: fx, fy, cx, cy */, const float* c2w /* host: 3 x 4 row-major */,
+                      int inverse_y, int flip_x, int flip_y, int center, int ndc, float ndc_focal, float ndc_near, int64_t p0,
+                      int64_t n, float* rays_o, float* rays_d, float* viewdirs, void* stream) {
+  if (H <= 0 || W <= 0 || p0 < 0 || n < 0 || p0 + n > (int64_t)H * W) return DVGO_EINVAL;
+  if (n == 0) return 0;
+  if (!K4 || !c2w || !rays_o || !rays_d) return DVGO_EINVAL;
+  if (!dvgo_fits(n)) return DVGO_ERANGE;
+  ViewCam V;
+  for (int k = 0; k < 3; ++k) {
+    for (int m = 0; m < 3; ++m) V.R[k][m] = c2w[4 * k + m];
+    V.t[k] = c2w[4 * k + 3];
+  }
+  V.fx = K4[0]; V.fy = K4[1]; V.cx = K4[2]; V.cy = K4[3];
+  V.H = H; V.W = W; V.inverse_y = inverse_y; V.flip_x = flip_x; V.flip_y = flip_y; V.center = center; V.ndc = ndc;
+  V.ndc_focal = ndc_focal; V.ndc_near = ndc_near;
+  rays_of_view_kernel<<<dvgo_blocks(n, DVGO_BLOCK), DVGO_BLOCK, 0, (hipStream_t)stream>>>(V, p0, n, rays_o, rays_d, viewdirs);
+  DVGO_LAUNCH_CHECK();
+  return 0;
+}
+
 
 int dvgo_view_weight_accumulate(const float* rays_o, const float* rays_d, int64_t n_rays, const float* xyz_min,
                                 const float* xyz_max, float near, float far, float step, int n_samples, int X, int Y,

@@ -113,6 +113,33 @@ class grid_rows_capture:
         return False
 
 
+class brick_union:
+    """Context manager of a data-parallel training step (train.TrainStep, world > 1): the march's brick scatter then moves
+    the grid gradient between the ranks as whole brick tiles.
+      forward : the per-brick counts of every rank are summed (one 4 * n_bricks byte all-reduce, started right after
+                march_density and waited for behind the local scans), `dvgo_brick_scan` turns the sum into the list of the
+                bricks ANY rank touched, and its length rides on the forward's one host read;
+      backward: every rank writes one 512 x 16 tile per listed brick (zeros where it has no sample), ONE all-reduce sums the
+                compact tile buffer, and every rank applies the same masked Adam update from the summed tiles
+                (grid_rows_capture.adam) -- parameters and moments stay replicated, no dense gradient, no host-side index.
+    `.sparse` (after the forward): True when the tile path takes the step -- the union is at most `max_frac` of the bricks;
+    otherwise the backward produces dense gradients for the reduce-scatter path.  Rank-invariant by construction (it is
+    decided from the all-reduced counts)."""
+    _active = None
+
+    def __init__(self, group=None, max_frac=0.5):
+        self.group, self.max_frac = group, max_frac
+        self.sparse, self.n_union, self.n_bricks, self.bytes_on_wire = None, 0, 0, 0
+
+    def __enter__(self):
+        brick_union._active = self
+        return self
+
+    def __exit__(self, *exc):
+        brick_union._active = None
+        return False
+
+
 def split_grid_rows(G, density, k0):
     """Combined gradient rows -> (density.grad, k0.grad) in the parameters' own layouts."""
     gk = torch.empty_like(k0, memory_format=torch.preserve_format)
@@ -177,10 +204,12 @@ class _FusedMarch(torch.autograd.Function):
                 brick_cnt = torch.zeros(nb, dtype=torch.int32, device=dev)
                 brick_off = torch.empty((3, nb + 1), dtype=torch.int32, device=dev)    # list offsets, extra items, non-empty bricks
                 brick_cur = torch.empty(nb, dtype=torch.int32, device=dev)
-                # heavy bricks: extra work items <= entries / slice, entries <= 8 per record slot (the slice tables are
-                # built for up to 2^28 entries; render-sized batches beyond that run one workgroup per brick)
-                if 8 * cap < 1 << 28:
-                    slice_len = BRICK_SLICE or L.lib().dvgo_brick_slice()
+                # heavy bricks: extra work items <= entries / slice, entries <= 8 per record slot.  The packed scan of
+                # csrc/scan.h has 28 bits for entries and 18 each for extra items and non-empty bricks: beyond that
+                # (render-sized batches, 512^3 grids) every brick runs as one workgroup
+                sl = BRICK_SLICE or L.lib().dvgo_brick_slice()
+                if 8 * cap < 1 << 28 and nb < 1 << 18 and 8 * max(cap, 1) // sl < 1 << 18:
+                    slice_len = sl
                     n_extra_max = 8 * max(cap, 1) // slice_len
                     extra_brick = torch.empty(max(n_extra_max, 1), dtype=torch.int32, device=dev)
             mask = cfg.mask
@@ -196,6 +225,12 @@ class _FusedMarch(torch.autograd.Function):
                    ptr(brick_off[1] if extra_brick is not None else None),
                    ptr(brick_off[2] if extra_brick is not None else None), ptr(extra_brick), _int(n_extra_max),
                    _int(slice_len), st)
+            bu = brick_union._active if (bricks and extra_brick is not None and ctx.needs_input_grad[0]) else None
+            union_cnt = union_work = None
+            if bu is not None:
+                import torch.distributed as dist
+                union_cnt = brick_cnt.clone()                       # (the local scan below clears the counters)
+                union_work = dist.all_reduce(union_cnt, op=dist.ReduceOp.SUM, group=bu.group, async_op=True)
             n_entries = 0
             if tail:
                 pass                    # the last workgroup of march_density has written off3 and the brick tables
@@ -212,12 +247,22 @@ class _FusedMarch(torch.autograd.Function):
                            ptr(brick_off[1] if extra_brick is not None else None),
                            ptr(brick_off[2] if extra_brick is not None else None), ptr(extra_brick), _int(n_extra_max),
                            _int(slice_len), st)
+            union_tabs = None
+            if bu is not None:
+                union_work.wait()
+                union_tabs = torch.empty((4, nb + 1), dtype=torch.int32, device=dev)     # off, cursor, extra, active
+                L.call('dvgo_brick_scan', ptr(union_cnt), _int(nb), ptr(union_tabs[0]), ptr(union_tabs[1]), ptr(union_tabs[2]),
+                       ptr(union_tabs[3]), ptr(union_tabs[1]), _int(0), _int(1 << 30), st)
             if capacity and stride > 0 and bricks:
                 # training step (train.py): the surviving-sample count stays on the device.  The outputs are sized by
                 # their upper bound -- every step of every ray -- and every consumer is handed off3[N] as a device
                 # pointer (`m_dev`): no host synchronisation in the forward at all.  Rows past the count are garbage.
                 M3 = stride * N
                 n_entries = 8 * M3                              # a sample touches at most 2 x 2 x 2 bricks
+            elif bricks and bu is not None:
+                M3, n_entries, n_union = torch.stack((off3[-1], brick_off[0, -1].long(), union_tabs[3, -1].long())).tolist()
+                bu.n_union, bu.n_bricks = n_union, nb
+                bu.sparse = n_union <= bu.max_frac * nb
             elif bricks:
                 M3, n_entries = torch.stack((off3[-1], brick_off[0, -1].long())).tolist()   # the one host sync
             else:
@@ -234,6 +279,7 @@ class _FusedMarch(torch.autograd.Function):
         ctx.cfg = cfg
         ctx.geom = (X, Y, Z, C, sC, sX, sY, sZ, stride, N)
         ctx.bricks = (brick_off, brick_cur, brick_cnt, extra_brick, slice_len, n_entries) if bricks else None
+        ctx.union = (bu, union_tabs[3], bu.n_union) if (bu is not None and bu.sparse) else None
         ctx.padded = bool(capacity and stride > 0 and bricks)
         ctx.density_meta, ctx.k0_meta = density, k0
         ctx.save_for_backward(rec2, n2, n_steps, cum if cum is not None else n_steps, off3, start, dirs, last,
@@ -287,11 +333,33 @@ class _FusedMarch(torch.autograd.Function):
                 cap = grid_rows_capture._active
                 fuse = (cap is not None and cap.adam is not None and not cap.stepped and cap.density is ctx.density_meta
                         and cap.k0 is ctx.k0_meta)
-                if fuse:
+                if fuse and ctx.union is not None:
+                    # data parallel, sparse scene: tiles of the bricks any rank touched -> one all-reduce -> the same masked
+                    # Adam update from the summed tiles on every rank
+                    import torch.distributed as dist
+                    bu, active_u, n_union = ctx.union
+                    TS = (C + 4) // 4 * 4
+                    tiles = torch.empty((max(n_union, 1), 512 * TS), dtype=torch.float32, device=dev)
+                    items_u = (items[0], items[1], ptr(active_u)) + items[3:]
+                    nulls = (ptr(None), ptr(None), ptr(None), _flt(0), _int(0), ptr(None), ptr(None), ptr(None), _flt(0), _int(0),
+                             _flt(0), _flt(0), _flt(0), ptr(None))
+                    L.call('dvgo_brick_accumulate', *items_u, ptr(recs), ptr(start), ptr(dirs), _flt(cfg.stepdist),
+                           cfg.xyz_min_h, cfg.xyz_max_h, ptr(g_feat), _int(C), _int(X), _int(Y), _int(Z), ptr(None), ptr(None),
+                           *nulls, ptr(tiles), _int(2), st)
+                    if n_union > 0:
+                        dist.all_reduce(tiles[:n_union], op=dist.ReduceOp.SUM, group=bu.group)
+                    bu.bytes_on_wire = n_union * 512 * TS * 4
+                    tail = cap.adam()
+                    L.call('dvgo_brick_accumulate', *items_u, ptr(None), ptr(None), ptr(None), _flt(cfg.stepdist),
+                           cfg.xyz_min_h, cfg.xyz_max_h, ptr(None), _int(C), _int(X), _int(Y), _int(Z), ptr(None), ptr(None),
+                           *tail, ptr(tiles), _int(3), st)
+                    cap.stepped = True
+                    return None, None, None, None, None, None
+                if fuse and brick_union._active is None:
                     tail = cap.adam()
                     L.call('dvgo_brick_accumulate', *items, ptr(recs), ptr(start), ptr(dirs), _flt(cfg.stepdist),
                            cfg.xyz_min_h, cfg.xyz_max_h, ptr(g_feat), _int(C), _int(X), _int(Y), _int(Z), ptr(None), ptr(None),
-                           *tail, st)
+                           *tail, ptr(None), _int(0), st)
                     cap.stepped = True
                     return None, None, None, None, None, None
                 grad_k0 = torch.empty_like(ctx.k0_meta, memory_format=torch.preserve_format)
@@ -300,7 +368,7 @@ class _FusedMarch(torch.autograd.Function):
                 L.call('dvgo_brick_accumulate', *items, ptr(recs), ptr(start), ptr(dirs), _flt(cfg.stepdist),
                        cfg.xyz_min_h, cfg.xyz_max_h, ptr(g_feat), _int(C), _int(X), _int(Y), _int(Z), ptr(grad_k0),
                        ptr(grad_density), ptr(None), ptr(None), ptr(None), _flt(0), _int(0),
-                       ptr(None), ptr(None), ptr(None), _flt(0), _int(0), _flt(0), _flt(0), _flt(0), ptr(None), st)
+                       ptr(None), ptr(None), ptr(None), _flt(0), _int(0), _flt(0), _flt(0), _flt(0), ptr(None), ptr(None), _int(0), st)
                 return grad_density, grad_k0, None, None, None, None
 
             # worth its two extra full-grid passes (zero 64 B, split 116 B per voxel) from ~1 kept sample per 6 voxels

@@ -72,6 +72,9 @@ class MaskedAdam(torch.optim.Optimizer):
         # ([0] feature grid, [1] density grid, [2 + g] small tensors of param group g) and the kernels read them from
         # there, so that a replayed HIP graph sees the values of ITS step; `hyper_begin` fills it
         self.hyper_dev, self._hyper_pin = None, None
+        # `hyper_begin` has uploaded the step sizes of the step about to run; consumed by that step's `step()`.  Any other
+        # caller of `step()` (a user loop, a tool) gets the host-side step sizes as usual
+        self._hyper_fresh = False
         super().__init__(params, {'lr': lr, 'betas': betas, 'eps': eps})
 
     def set_pervoxel_lr(self, count):
@@ -170,6 +173,7 @@ class MaskedAdam(torch.optim.Optimizer):
                             self._state_of(p)['step'] += 1
         self.hyper_dev.copy_(vals, non_blocking=True)
         done.record()
+        self._hyper_fresh = True
 
     def grid_step_args(self, density, k0):
         """Counts one step for both grids and returns the Adam argument tail of dvgo_brick_accumulate
@@ -183,7 +187,7 @@ class MaskedAdam(torch.optim.Optimizer):
                 _int(1 if gk.get('skip_zero_grad', False) else 0),
                 ptr(density), ptr(sd['exp_avg']), ptr(sd['exp_avg_sq']), _flt(adam_step_size(gd['lr'], b1, b2, sd['step'])),
                 _int(1 if gd.get('skip_zero_grad', False) else 0), _flt(b1), _flt(b2), _flt(gk['eps']),
-                ptr(self.hyper_dev[0:2]) if self.hyper_dev is not None else ptr(None))
+                ptr(self.hyper_dev[0:2]) if (self.hyper_dev is not None and self._hyper_fresh) else ptr(None))
 
     @torch.no_grad()
     def step_grid_rows(self, density, k0, G):
@@ -251,4 +255,5 @@ class MaskedAdam(torch.optim.Optimizer):
             for stp, items in by_step.items():
                 for i in range(0, len(items), 16):
                     adam_upd_multi(items[i:i + 16], stp, b1, b2, group['lr'], group['eps'],
-                                   self.hyper_dev[2 + gi:3 + gi] if self.hyper_dev is not None else None)
+                                   self.hyper_dev[2 + gi:3 + gi] if (self.hyper_dev is not None and self._hyper_fresh) else None)
+        self._hyper_fresh = False

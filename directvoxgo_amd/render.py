@@ -54,7 +54,30 @@ def ndc_rays(H, W, focal, near, rays_o, rays_d):
     return torch.stack([o0, o1, o2], -1), torch.stack([d0, d1, d2], -1)
 
 
+def rays_of_view(H, W, K, c2w, ndc, inverse_y, flip_x, flip_y, mode='center', p0=0, n=None, device=None):
+    """The rays of pixels [p0, p0 + n) of a view, flat [n, 3], written by ONE kernel (csrc/maintain.hip: rays_of_view) --
+    the device form of `get_rays_of_a_view` (lib/ray_utils.py:9-85) for the deterministic pixel modes."""
+    import ctypes
+    from . import _lib as L
+    from ._lib import _flt, _i64, _int, ptr
+    assert mode in ('center', 'lefttop')
+    dev = torch.device(device) if device is not None else (c2w.device if isinstance(c2w, torch.Tensor) else torch.device('cuda'))
+    n = H * W - p0 if n is None else n
+    c = np.asarray(c2w.detach().cpu() if isinstance(c2w, torch.Tensor) else c2w, dtype=np.float32)[:3, :4]
+    K4 = (ctypes.c_float * 4)(float(K[0][0]), float(K[1][1]), float(K[0][2]), float(K[1][2]))
+    C12 = (ctypes.c_float * 12)(*[float(v) for v in c.reshape(-1)])
+    out = torch.empty((3, max(n, 1), 3), dtype=torch.float32, device=dev)
+    with L.device_of(out):
+        L.call('dvgo_rays_of_view', _int(H), _int(W), K4, C12, _int(bool(inverse_y)), _int(bool(flip_x)), _int(bool(flip_y)),
+               _int(mode == 'center'), _int(bool(ndc)), _flt(float(K[0][0])), _flt(1.0), _i64(p0), _i64(n), ptr(out[0]), ptr(out[1]),
+               ptr(out[2]), L.stream_of(out))
+    return out[0, :n], out[1, :n], out[2, :n]
+
+
 def get_rays_of_a_view(H, W, K, c2w, ndc, inverse_y, flip_x, flip_y, mode='center'):
+    if isinstance(c2w, torch.Tensor) and c2w.is_cuda and mode in ('center', 'lefttop'):
+        o, d, v = rays_of_view(H, W, K, c2w, ndc, inverse_y, flip_x, flip_y, mode)
+        return o.view(H, W, 3), d.view(H, W, 3), v.view(H, W, 3)
     rays_o, rays_d = get_rays(H, W, K, c2w, inverse_y=inverse_y, flip_x=flip_x, flip_y=flip_y, mode=mode)
     viewdirs = rays_d / rays_d.norm(dim=-1, keepdim=True)
     if ndc:
@@ -75,15 +98,24 @@ def render_viewpoints(model, render_poses, HW, Ks, ndc, render_kwargs, flip_x=Fa
     mine = {}
     for i in range(rank, len(render_poses), world):
         H, W = int(HW[i][0]), int(HW[i][1])
-        c2w = torch.as_tensor(np.asarray(render_poses[i]), dtype=torch.float32, device=dev)
-        rays_o, rays_d, viewdirs = get_rays_of_a_view(H, W, Ks[i], c2w, ndc, inverse_y=kwargs.get('inverse_y', False),
-                                                      flip_x=flip_x, flip_y=flip_y)
-        rays_o, rays_d, viewdirs = (t.flatten(0, -2).contiguous() for t in (rays_o, rays_d, viewdirs))
+        n_pix = H * W
+        on_gpu = dev.type == 'cuda'
+        if not on_gpu:
+            c2w = torch.as_tensor(np.asarray(render_poses[i]), dtype=torch.float32, device=dev)
+            rays_o, rays_d, viewdirs = get_rays_of_a_view(H, W, Ks[i], c2w, ndc, inverse_y=kwargs.get('inverse_y', False),
+                                                          flip_x=flip_x, flip_y=flip_y)
+            rays_o, rays_d, viewdirs = (t.flatten(0, -2).contiguous() for t in (rays_o, rays_d, viewdirs))
         out_rgb, out_depth = [], []
-        n_chunks = rays_o.shape[0] // chunk + 1                    # run.py:91, last chunk may be empty
+        n_chunks = n_pix // chunk + 1                              # run.py:91, last chunk may be empty
         for c in range(n_chunks):
-            sl = slice(chunk * c, chunk * (c + 1))
-            res = model(rays_o[sl], rays_d[sl], viewdirs[sl], global_step=c, **kwargs)
+            p0 = chunk * c
+            n = max(0, min(chunk, n_pix - p0))
+            if on_gpu:       # the chunk's rays straight from the ray-generation kernel: no [H, W, 3] tensors per view
+                ro, rd, vd = rays_of_view(H, W, Ks[i], render_poses[i], ndc, kwargs.get('inverse_y', False), flip_x, flip_y,
+                                          p0=min(p0, n_pix), n=n, device=dev)
+            else:
+                ro, rd, vd = rays_o[p0:p0 + n], rays_d[p0:p0 + n], viewdirs[p0:p0 + n]
+            res = model(ro, rd, vd, global_step=c, **kwargs)
             out_rgb.append(res['rgb_marched']); out_depth.append(res['depth'])
         mine[i] = (torch.cat(out_rgb).reshape(H, W, 3), torch.cat(out_depth).reshape(H, W, 1))
     if distributed and world > 1:

@@ -21,7 +21,7 @@ import torch.distributed as dist
 import torch.nn as nn
 
 from .masked_adam import MaskedAdam
-from .fused import grid_rows_capture, split_grid_rows
+from .fused import brick_union, grid_rows_capture, split_grid_rows
 from .shade import defer_wgrad
 
 def flat_view(t):
@@ -166,6 +166,15 @@ class TrainStep:
         self._touched_frac = None            # fraction of voxels in the last union; None: not probed yet
         self._steps_since_probe = 0
         self.overlap_wgrad = overlap_wgrad    # colour-head weight gradients on a second stream (shade.defer_wgrad)
+        # data parallel, fused HIP model: the grid gradient travels as the tiles of the bricks any rank touched and every
+        # rank applies the same fused Adam update (fused.brick_union); used while that union is at most BRICK_SPARSE_MAX of
+        # the bricks, decided per step from the all-reduced brick counts
+        self.brick_sparse = True
+        self.last_mode = None                 # 'bricks' / 'sharded' / 'allreduce' / 'touched' / 'single': what the last step used
+        self.last_wire_bytes = 0
+        # the sharded update leaves every rank with the moments of its own X-slab only: before any step that updates the
+        # whole grid on every rank (tiles, touched voxels, all-reduce fallback) the slabs are gathered once
+        self._moments_sharded = False
         self.fused_loss = fused_loss
         self.cfg = cfg_train
         self.render_kwargs = render_kwargs
@@ -213,6 +222,7 @@ class TrainStep:
     # TOUCHED_MAX of the grid (decided from the previous union, identical on all ranks; re-probed every
     # PROBE_EVERY steps while the dense path is in use).
     TOUCHED_MAX = 0.35
+    BRICK_SPARSE_MAX = 0.5
     PROBE_EVERY = 64
     OVERLAP_MIN_SAMPLES = 600000
 
@@ -285,6 +295,8 @@ class TrainStep:
     def _sharded_update(self, shards):
         """Adam on the owned slabs, then the parameters travel.  Returns the all-gather handles."""
         works = []
+        self._moments_sharded = True
+        self.optimizer._dvgo_sharded_by = self          # (checkpoint.save_checkpoint gathers the slabs before it writes)
         for p, fp, fg, lo, hi, _ in shards:
             self.optimizer.step_shard(p, fp, fg, lo, hi)
             p.grad = None                      # consumed: optimizer.step() below skips the grids
@@ -312,7 +324,14 @@ class TrainStep:
                 n = flat.numel() // self.world
                 dist.all_gather_into_tensor(flat, flat[rank * n:(rank + 1) * n].clone(), group=self.pg)
             done = True
+        self._moments_sharded = False
         return done
+
+    def _whole_grid_update_ahead(self):
+        """Call (on every rank: it is a collective when it does anything) before a step in which every rank updates the
+        WHOLE grid: after sharded steps each rank only holds current moments for its own slab."""
+        if self._moments_sharded:
+            self.gather_optimizer_state()
 
     def _sample_count(self, res):
         """Number of surviving samples of the step, without waiting for it: exact when the forward read it back anyway,
@@ -422,42 +441,55 @@ class TrainStep:
         keep_on_device = (self.sync_free and self.fused_loss and rays_o.is_cuda and hasattr(model, 'can_keep_count_on_device')
                           and model.can_keep_count_on_device())
         extra = {'_capacity': True} if keep_on_device else {}
-        res = model(rays_o, rays_d, viewdirs, global_step=global_step, **self.render_kwargs, **extra)
-        self.optimizer.zero_grad(set_to_none=True)
-        loss_fn = fused_render_loss if (self.fused_loss and res['rgb_marched'].is_cuda) else render_loss
-        loss = loss_fn(res, target, n_global, cfg)
-        if self.track_mse:
-            self.last_mse = cfg['weight_main'] * (res['rgb_marched'].detach() - target).pow(2).sum() / (3 * n_global)
-        # backward order: ... colour-head data gradient -> grid scatters.  One GPU: the colour head's weight-gradient
-        # kernel runs on a second stream beside the scatters.  Data parallel: it is postponed until the grid
-        # all-reduce has been STARTED -- its persistent workgroups fill every CU, and RCCL's kernels, arriving
-        # second, would sit behind them; arriving first they keep their CUs and the two overlap
         tv_now = (cfg['tv_after'] < global_step < cfg['tv_before'] and global_step % cfg['tv_every'] == 0 and
                   (cfg['weight_tv_density'] > 0 or cfg['weight_tv_k0'] > 0))
         density, k0 = getattr(model, 'density', None), getattr(model, 'k0', None)
-        own = (self.rows_adam and self.world == 1 and not tv_now and isinstance(self.optimizer, MaskedAdam)
+        # may the march's brick scatter apply the grid update itself?  One GPU: from its own tiles.  Data parallel: from the
+        # all-reduced tiles of the bricks any rank touched (fused.brick_union) while that union stays small.
+        own = (self.rows_adam and not tv_now and isinstance(self.optimizer, MaskedAdam)
                and isinstance(density, nn.Parameter) and isinstance(k0, nn.Parameter) and density.is_cuda)
         fuse_adam = own and self.optimizer.can_fuse_grid_step(density, k0)
-        use_rows = fuse_adam or (own and self.optimizer.can_step_grid_rows(density, k0))
-        self.last_fused_adam = bool(fuse_adam)       # (bench.py: which bytes the scatter launch is credited with)
-        opt = self.optimizer
-        rows = (grid_rows_capture(density, k0, adam=(lambda: opt.grid_step_args(density, k0)) if fuse_adam else None)
-                if use_rows else contextlib.nullcontext())
-        # the second stream pays on kernel-bound steps (the weight-gradient kernel beside the grid scatter: -0.3 ms at
-        # 2 M samples) and costs on launch-bound ones (stream switches and event records on the host: +0.1 ms at 0.2 M)
-        if getattr(self, '_capturing', False):       # no host reads while a graph is being captured: the last count seen
-            n_samples = self._m3_seen if self._m3_seen is not None else res['weights'].shape[0]
-        else:
-            n_samples = self._sample_count(res)
-        side = self.overlap_wgrad and self.world == 1 and n_samples >= self.OVERLAP_MIN_SAMPLES
-        with defer_wgrad(side_stream=side) as deferred, rows as cap:
-            _FusedLoss.unit_grad = True
-            try:
-                loss.backward()
-            finally:
-                _FusedLoss.unit_grad = False
+        dp_bricks = bool(fuse_adam and self.world > 1 and self.brick_sparse and getattr(model, 'fused', False))
+        if self.world > 1:
+            own = fuse_adam = False                    # (dense gradients unless the tile path takes the step)
+        with (brick_union(self.pg, self.BRICK_SPARSE_MAX) if dp_bricks else contextlib.nullcontext()) as bu:
+            res = model(rays_o, rays_d, viewdirs, global_step=global_step, **self.render_kwargs, **extra)
+            self.optimizer.zero_grad(set_to_none=True)
+            loss_fn = fused_render_loss if (self.fused_loss and res['rgb_marched'].is_cuda) else render_loss
+            loss = loss_fn(res, target, n_global, cfg)
+            if self.track_mse:
+                self.last_mse = cfg['weight_main'] * (res['rgb_marched'].detach() - target).pow(2).sum() / (3 * n_global)
+            tiles = bool(dp_bricks and bu.sparse)      # identical on every rank: decided from the all-reduced brick counts
+            if tiles:
+                self._whole_grid_update_ahead()
+            # backward order: ... colour-head data gradient -> grid scatters.  One GPU: the colour head's weight-gradient
+            # kernel runs on a second stream beside the scatters.  Data parallel: it is postponed until the grid
+            # all-reduce has been STARTED -- its persistent workgroups fill every CU, and RCCL's kernels, arriving
+            # second, would sit behind them; arriving first they keep their CUs and the two overlap
+            use_rows = fuse_adam or tiles or (own and self.optimizer.can_step_grid_rows(density, k0))
+            self.last_fused_adam = bool(fuse_adam or tiles)       # (bench.py: which bytes the scatter launch is credited with)
+            opt = self.optimizer
+            rows = (grid_rows_capture(density, k0, adam=(lambda: opt.grid_step_args(density, k0)) if (fuse_adam or tiles) else None)
+                    if use_rows else contextlib.nullcontext())
+            # the second stream pays on kernel-bound steps (the weight-gradient kernel beside the grid scatter: -0.3 ms at
+            # 2 M samples) and costs on launch-bound ones (stream switches and event records on the host: +0.1 ms at 0.2 M)
+            if getattr(self, '_capturing', False):       # no host reads while a graph is being captured: the last count seen
+                n_samples = self._m3_seen if self._m3_seen is not None else res['weights'].shape[0]
+            else:
+                n_samples = self._sample_count(res)
+            side = self.overlap_wgrad and self.world == 1 and n_samples >= self.OVERLAP_MIN_SAMPLES
+            with defer_wgrad(side_stream=side) as deferred, rows as cap:
+                _FusedLoss.unit_grad = True
+                try:
+                    loss.backward()
+                finally:
+                    _FusedLoss.unit_grad = False
+        self.last_mode = 'single' if self.world == 1 else None
+        self.last_wire_bytes = 0
         if use_rows and cap.stepped:
             assert density.grad is None and k0.grad is None    # both grids were updated inside the backward (csrc/brick.hip)
+            if tiles:
+                self.last_mode, self.last_wire_bytes = 'bricks', bu.bytes_on_wire
         elif use_rows and cap.G is not None:
             if density.grad is None and k0.grad is None:
                 self.optimizer.step_grid_rows(density, k0, cap.G)  # (.grad of the two grids is None: step() below skips them)
@@ -466,11 +498,26 @@ class TrainStep:
                 density.grad = gd if density.grad is None else density.grad + gd
                 k0.grad = gk if k0.grad is None else k0.grad + gk
             cap.G = None
-        works = self.reduce_grids_async()
+        if self.world > 1 and not (use_rows and cap.stepped):
+            # every rank must enter the same collectives: a rank whose shard produced no gradient for a grid brings zeros
+            for p in (density, k0):
+                if isinstance(p, nn.Parameter) and p.requires_grad and p.grad is None:
+                    p.grad = torch.zeros_like(p, memory_format=torch.preserve_format)
+        # (dp_bricks: the all-reduced brick counts have just said that the scene is dense -- no touched-voxel probe)
+        works = [] if ((use_rows and cap.stepped) or dp_bricks) else self.reduce_grids_async()
         shards = None
-        if self.world > 1 and not works:            # (the compacted touched-voxel reduction took the sparse case)
+        if self.world > 1 and not works and not (use_rows and cap.stepped):   # (else the compacted reduction took the step)
             shards = self._grid_shards()
-            works = self._sharded_reduce_start(shards) if shards else self._all_reduce_grids()
+            if shards:
+                works = self._sharded_reduce_start(shards)
+                self.last_mode = 'sharded'
+            else:
+                self._whole_grid_update_ahead()
+                works = self._all_reduce_grids()
+                self.last_mode = 'allreduce'
+        elif works:
+            self._whole_grid_update_ahead()
+            self.last_mode = 'touched'
         deferred.flush()
         self.reduce_small()
         for wk in works:

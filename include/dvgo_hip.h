@@ -344,6 +344,14 @@ int dvgo_brick_accumulate(const int32_t* brick_off, const int32_t* extra_off, co
                           int masked_density, float beta1, float beta2, float eps,
                           const float* step_sizes_dev /* NULL, or device {step_size_k0, step_size_density}: read instead of
                                                          the two float arguments (a captured step replays with new values) */,
+                          float* tiles, int tiles_mode
+                                      /* data parallel (ray-sharded ranks, replicated grids): the gradient travels as whole brick
+                                         tiles of 512 x round_up(C + 1, 4) floats, one per brick of `active` = the bricks ANY rank
+                                         touched (active[n_bricks] = their number; from dvgo_brick_scan over the all-reduced
+                                         counts).  tiles_mode 2: accumulate this rank's lists and write tiles[i] for every
+                                         brick active[i] (zeros where this rank has no entry); the caller all-reduces `tiles`;
+                                         tiles_mode 3: read tiles[i] and apply the (masked) Adam update of brick active[i] from
+                                         it (lists / recs / rays unused).  0: neither. */,
                           void* stream);
 
 /* Combined gradient rows G [n_vox][row_stride] (built by the two calls above) -> the channels-last feature
@@ -365,6 +373,13 @@ int dvgo_view_weight_accumulate(const float* rays_o, const float* rays_d, int64_
                                 const float* xyz_max, float near, float far, float step, int n_samples, int X, int Y,
                                 int Z, float* acc, void* stream);
 int dvgo_view_count_commit(float* acc, float* count, int64_t n_vox, void* stream);
+/* dvgo_rays_of_view: rays of the pixels [p0, p0 + n) (row-major) of one view -- lib/ray_utils.py:9-85: get_rays (pixel
+ *   coordinates, `center` = mode 'center' else 'lefttop', flips, inverse_y), viewdirs = rays_d / |rays_d| (before the NDC
+ *   warp, as get_rays_of_a_view), ndc != 0: ndc_rays(H, W, ndc_focal, ndc_near, ...).  K4 = {fx, fy, cx, cy} and c2w (3 x 4,
+ *   row-major) are HOST pointers; outputs [n, 3] device arrays (viewdirs may be NULL). */
+int dvgo_rays_of_view(int H, int W, const float* K4, const float* c2w, int inverse_y, int flip_x, int flip_y, int center,
+                      int ndc, float ndc_focal, float ndc_near, int64_t p0, int64_t n,
+                      float* rays_o, float* rays_d, float* viewdirs, void* stream);
 int dvgo_maskout_near_cam(float* density, const float* grid_x, const float* grid_y, const float* grid_z, int X, int Y, int Z,
                           const float* cam_o, int n_cam, float near, float value, void* stream);
 

@@ -98,13 +98,13 @@ class TorchMaskedAdam(torch.optim.Optimizer):
 
 def run_steps(model, batch, rank, world, n_steps=3, mode='dense', out=None):
     cfg = dict(FINE_TRAIN, weight_entropy_last=0.01, weight_rgbper=0.05)
-    if mode in ('sharded', 'sharded_off'):
+    if mode in ('sharded', 'sharded_off', 'flip'):
         # Adam with the masked rule on the grids, the sharded update on (reduce-scatter -> slab Adam -> all-gather)
         # or off (all-reduce -> full Adam on every rank)
         opt = TorchMaskedAdam([{'params': [model.density], 'lr': 0.1, 'skip_zero_grad': True},
                                {'params': [model.k0], 'lr': 0.1, 'skip_zero_grad': True},
                                {'params': list(model.rgbnet.parameters()), 'lr': 1e-2}])
-        step = TrainStep(model, cfg, dict(bg=1), optimizer=opt, touched_reduce=False, shard_grids=(mode == 'sharded'))
+        step = TrainStep(model, cfg, dict(bg=1), optimizer=opt, touched_reduce=False, shard_grids=(mode != 'sharded_off'))
         step.sharded_steps = 0
         orig = step._sharded_update
         def counted(shards):
@@ -121,8 +121,17 @@ def run_steps(model, batch, rank, world, n_steps=3, mode='dense', out=None):
     n = batch[0].shape[0] // world
     shard = tuple(t[rank * n:(rank + 1) * n] for t in batch)
     losses = []
+    modes_seen = []
     for s in range(n_steps):
+        if mode == 'flip' and s == 2:
+            # the reduction mode changes mid-run -- two sharded steps (each rank updates the moments of its
+            # own X-slab only), then the compacted touched-voxel reduction with a full update on every rank
+            step.touched_reduce = True
+            step.TOUCHED_MAX = 2.0
         losses.append(step(*shard, global_step=s))
+        modes_seen.append(step.last_mode)
+    if mode == 'flip' and world > 1:
+        assert modes_seen == ['sharded', 'sharded', 'touched', 'touched'], modes_seen
     if mode == 'sharded' and world > 1:
         assert step.sharded_steps == n_steps                    # the slab path really ran
     if mode == 'sharded_off':
@@ -144,11 +153,22 @@ def _worker(rank, world, port, q, mode='dense'):
     torch.set_num_threads(1)
     model = ToyModel()
     out = {}
-    losses = run_steps(model, make_batch(32), rank, world, mode=mode, out=out)
+    losses = run_steps(model, make_batch(32), rank, world, mode=mode, out=out, n_steps=4 if mode == 'flip' else 3)
     dist.all_reduce(losses)           # per-rank shares of the global loss add up to it
     moments = None
-    if mode == 'sharded':             # what a checkpoint of a data-parallel run needs: every rank's slab of the moments
-        assert out['step'].gather_optimizer_state()
+    if mode == 'flip':                # after the flip every rank holds the complete, identical state
+        for p in (model.density, model.k0):
+            for key in ('exp_avg', 'exp_avg_sq'):
+                mine = out['step'].optimizer.state[p][key].clone()
+                other = mine.clone()
+                dist.all_reduce(other, op=dist.ReduceOp.MAX)
+                assert torch.equal(mine, other), f'ranks disagree on {key}'
+        moments = _moments(model, out['step'])
+    if mode == 'sharded':             # what a checkpoint of a data-parallel run needs: every rank's slab of the moments:
+        from directvoxgo_amd.checkpoint import save_checkpoint        # the save helper gathers them itself
+        assert out['step']._moments_sharded
+        save_checkpoint(None, model, out['step'].optimizer, 3)        # (path None: this rank does not write)
+        assert not out['step']._moments_sharded
         moments = _moments(model, out['step'])
     if rank == 0:
         # numpy: pickled by value (torch tensors would travel as shared-memory handles of a process about to exit)
@@ -166,13 +186,14 @@ def _free_port():
 
 
 @pytest.mark.timeout(120)
-@pytest.mark.parametrize('mode', ['dense', 'touched', 'adaptive', 'sharded', 'sharded_off'])
+@pytest.mark.parametrize('mode', ['dense', 'touched', 'adaptive', 'sharded', 'sharded_off', 'flip'])
 def test_two_ranks_equal_one_process(mode):
     """`touched`: the grid gradients travel as the compacted union of the voxels either rank touched.
     `sharded`: reduce-scatter of the grid gradients, Adam on the owned X-slab only, all-gather of the parameters."""
     ref_model = ToyModel()
     ref_out = {}
-    ref_losses = run_steps(ref_model, make_batch(32), 0, 1, mode=mode if mode.startswith('sharded') else 'dense', out=ref_out)
+    ref_losses = run_steps(ref_model, make_batch(32), 0, 1, mode=mode if (mode.startswith('sharded') or mode == 'flip') else 'dense',
+                           out=ref_out, n_steps=4 if mode == 'flip' else 3)
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
@@ -186,7 +207,7 @@ def test_two_ranks_equal_one_process(mode):
     assert torch.allclose(torch.from_numpy(losses), ref_losses, rtol=1e-5, atol=1e-7)
     for k, v in ref_model.state_dict().items():
         assert torch.allclose(torch.from_numpy(sd[k]), v, rtol=1e-5, atol=1e-6), k
-    if mode == 'sharded':             # gathered moments == the single process's: the checkpoint of the run is complete
+    if mode in ('sharded', 'flip'):   # gathered moments == the single process's: the checkpoint of the run is complete
         for k, v in _moments(ref_model, ref_out['step']).items():
             assert np.allclose(moments[k], v, rtol=1e-5, atol=1e-8), k
             assert np.abs(moments[k]).sum() > 0

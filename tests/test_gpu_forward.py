@@ -282,3 +282,90 @@ def test_maskout_near_cam_vox_kernel():
     assert int(hit.sum()) > 100
     got = m.density[0, 0]
     assert torch.all((got == -100)[hit & ~edge]) and torch.all((got == before[0, 0])[~hit & ~edge])
+
+
+@pytest.mark.parametrize('flags', [dict(), dict(inverse_y=True), dict(flip_x=True, flip_y=True), dict(ndc=True), dict(mode='lefttop')])
+def test_rays_of_view_kernel_matches_the_reference_ray_generation(flags):
+    """csrc/maintain.hip rays_of_view (one launch per view / chunk) against lib/ray_utils.py:9-85: the rays the imported
+    reference produced (tests/golden/rays.npz, pixel-centre pinhole views) and, for the flag combinations the fixture does
+    not hold (inverse_y, flips, NDC, 'lefttop'), the torch statement of the same formulas evaluated on the CPU."""
+    from conftest import load_golden
+    from directvoxgo_amd.render import get_rays, ndc_rays, rays_of_view
+    from directvoxgo_amd.scenes import pose_spherical
+    g = load_golden('rays')
+    H, W, focal = int(g['H']), int(g['W']), float(g['focal'])
+    K = np.array([[focal, 0, 0.5 * W], [0, focal, 0.5 * H], [0, 0, 1]], np.float32)
+    ndc, mode = flags.get('ndc', False), flags.get('mode', 'center')
+    fl = {k: flags.get(k, False) for k in ('inverse_y', 'flip_x', 'flip_y')}
+    per = H * W
+    for vi, th in enumerate(g['thetas']):
+        pose = pose_spherical(float(th), float(g['phi']), float(g['radius']))
+        o, d, v = rays_of_view(H, W, K, pose.cuda(), ndc, fl['inverse_y'], fl['flip_x'], fl['flip_y'], mode)
+        if not flags:            # the reference's own output
+            sl = slice(vi * per, (vi + 1) * per)
+            np.testing.assert_allclose(o.cpu().numpy(), g['rays_o'][sl], atol=1e-6)
+            np.testing.assert_allclose(d.cpu().numpy(), g['rays_d'][sl], atol=1e-6)
+            np.testing.assert_allclose(v.cpu().numpy(), g['viewdirs'][sl], atol=1e-6)
+        ro, rd = get_rays(H, W, K, pose, mode=mode, **fl)                     # torch on the CPU
+        vd = rd / rd.norm(dim=-1, keepdim=True)
+        if ndc:
+            ro, rd = ndc_rays(H, W, focal, 1., ro, rd)
+        for a, b in ((o, ro), (d, rd), (v, vd)):
+            np.testing.assert_allclose(a.cpu().numpy(), b.reshape(-1, 3).numpy(), rtol=2e-6, atol=2e-6)
+        # a chunk in the middle of the image = the same rows of the whole view, bit for bit
+        p0, n = per // 3 + 5, min(1000, per - per // 3 - 5)
+        oc, dc, vc = rays_of_view(H, W, K, pose.cuda(), ndc, fl['inverse_y'], fl['flip_x'], fl['flip_y'], mode, p0=p0, n=n)
+        assert torch.equal(oc, o[p0:p0 + n]) and torch.equal(dc, d[p0:p0 + n]) and torch.equal(vc, v[p0:p0 + n])
+
+
+def _render_worker(rank, world, port, q):
+    import os
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    rgbs, depths = _render_views(distributed=True)
+    if rank == 0:
+        q.put((rgbs, depths))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _render_views(distributed):
+    from directvoxgo_amd.dvgo import DirectVoxGO
+    from directvoxgo_amd.render import render_viewpoints
+    from directvoxgo_amd.scenes import pose_spherical, synthetic_scene
+    sc = synthetic_scene(world=32, n_rays=64, seed=3, device='cuda')
+    torch.manual_seed(8)
+    m = DirectVoxGO(sc['xyz_min'], sc['xyz_max'], num_voxels=32 ** 3, num_voxels_base=32 ** 3, alpha_init=1e-2,
+                    fast_color_thres=1e-4, rgbnet_dim=12, rgbnet_width=64, rgbnet_direct=True).cuda()
+    with torch.no_grad():
+        m.density.copy_(sc['density']); m.k0.copy_(sc['k0']); m.mask_cache.mask.copy_(sc['mask'])
+    H = W = 40
+    K = np.array([[55.0, 0, 20], [0, 55.0, 20], [0, 0, 1]], np.float32)
+    poses = [pose_spherical(th, -30.0, 4.0).numpy() for th in (-120.0, -40.0, 10.0, 75.0, 160.0)]       # 5 views over 2 ranks
+    return render_viewpoints(m, poses, [(H, W)] * 5, [K] * 5, False, dict(near=sc['near'], far=sc['far'], bg=1, stepsize=0.5),
+                             chunk=512, distributed=distributed)
+
+
+@pytest.mark.timeout(300)
+def test_render_viewpoints_split_over_two_ranks_equals_one_process():
+    """BASELINE configs[4]'s multi-GPU split (run.py:57-143 per pose; SURVEY section 8e: images round-robin over the ranks,
+    gathered at the end): two gloo ranks sharing this GPU render views 0,2,4 / 1,3 and every rank ends up with all five
+    images, identical to the single-process render."""
+    import socket
+    import torch.multiprocessing as mp
+    ref_rgbs, ref_depths = _render_views(distributed=False)
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_render_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    rgbs, depths = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert rgbs.shape == (5, 40, 40, 3) and depths.shape == (5, 40, 40, 1)
+    assert np.array_equal(rgbs, ref_rgbs) and np.array_equal(depths, ref_depths)

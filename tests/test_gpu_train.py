@@ -271,6 +271,8 @@ def _dp_run(rank, world, mode, n_steps=3):
                      touched_reduce=(mode == 'touched'), shard_grids=(mode != 'allreduce'))
     if mode == 'touched':
         step.TOUCHED_MAX = 2.0
+    step.brick_sparse = mode in ('bricks', 'sharded_then_bricks')
+    step.BRICK_SPARSE_MAX = 2.0 if mode == 'bricks' else -1.0          # the tile path always / (for now) never
     if world > 1 and mode in ('dense', 'sharded_tv'):
         assert step._grid_shards is not None
         ran = []
@@ -279,21 +281,33 @@ def _dp_run(rank, world, mode, n_steps=3):
         step._ran_sharded = ran
     n = 2048 // world
     shard = tuple(sc[k][rank * n:(rank + 1) * n] for k in ('rays_o', 'rays_d', 'viewdirs', 'target'))
-    losses = [float(step(*shard, global_step=1 + s)) for s in range(n_steps)]
+    losses, modes = [], []
+    for s in range(n_steps + (1 if mode == 'sharded_then_bricks' else 0)):
+        if mode == 'sharded_then_bricks' and s == 2:
+            step.BRICK_SPARSE_MAX = 2.0          # two sharded steps (slab moments), then the tile path (whole-grid update)
+        losses.append(float(step(*shard, global_step=1 + s)))
+        modes.append(step.last_mode)
     torch.cuda.synchronize()
+    if world > 1 and mode == 'bricks':
+        assert modes == ['bricks'] * n_steps and step.last_wire_bytes > 0, modes
+    if world > 1 and mode == 'sharded_then_bricks':
+        assert modes == ['sharded', 'sharded', 'bricks', 'bricks'], modes
     if hasattr(step, '_ran_sharded'):
         assert len(step._ran_sharded) == n_steps        # reduce-scatter -> slab TV + Adam -> all-gather really ran
     return {k: v.detach().clone() for k, v in m.state_dict().items() if v.is_floating_point()}, losses
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize('mode', ['dense', 'allreduce', 'touched', 'sharded_tv'])
+@pytest.mark.parametrize('mode', ['dense', 'allreduce', 'touched', 'sharded_tv', 'bricks', 'sharded_then_bricks'])
 def test_two_ranks_on_one_gpu_equal_one_process(mode):
     """The product path under data parallelism: two ranks (gloo, both on this GPU), each marching half
     of the batch with the HIP kernels, reach the parameters of one process on the whole batch -- `dense`: reduce-scatter of
     the grid gradients, Adam on the owned X-slab, all-gather of the parameters; `sharded_tv`: the same with the sparse
     total-variation gradient added per slab; `allreduce`: the unsharded fallback; `touched`: the compacted
-    touched-voxel reduction."""
+    touched-voxel reduction; `bricks`: the gradient travels as the tiles of the bricks either rank touched (one all-reduce
+    of a compact buffer) and both ranks apply the same fused Adam update from the summed tiles;
+    `sharded_then_bricks`: the reduction mode changes mid-run (slab moments are gathered before the first whole-grid
+    update)."""
     import socket
     import torch.multiprocessing as mp
     ref_params, ref_losses = _dp_run(0, 1, mode)
