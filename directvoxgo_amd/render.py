@@ -87,7 +87,7 @@ def get_rays_of_a_view(H, W, K, c2w, ndc, inverse_y, flip_x, flip_y, mode='cente
 
 @torch.no_grad()
 def render_viewpoints(model, render_poses, HW, Ks, ndc, render_kwargs, flip_x=False, flip_y=False, chunk=65536,
-                      distributed=False):
+                      distributed=False, ray_kernel=True):
     """-> (rgbs [n,H,W,3], depths [n,H,W,1]) as numpy arrays (every rank gets all images when
     ``distributed``)."""
     assert len(render_poses) == len(HW) and len(HW) == len(Ks)
@@ -99,12 +99,18 @@ def render_viewpoints(model, render_poses, HW, Ks, ndc, render_kwargs, flip_x=Fa
     for i in range(rank, len(render_poses), world):
         H, W = int(HW[i][0]), int(HW[i][1])
         n_pix = H * W
-        on_gpu = dev.type == 'cuda'
+        on_gpu = dev.type == 'cuda' and ray_kernel        # (ray_kernel=False: the torch statement of lib/ray_utils.py, for A/B)
         if not on_gpu:
-            c2w = torch.as_tensor(np.asarray(render_poses[i]), dtype=torch.float32, device=dev)
-            rays_o, rays_d, viewdirs = get_rays_of_a_view(H, W, Ks[i], c2w, ndc, inverse_y=kwargs.get('inverse_y', False),
-                                                          flip_x=flip_x, flip_y=flip_y)
-            rays_o, rays_d, viewdirs = (t.flatten(0, -2).contiguous() for t in (rays_o, rays_d, viewdirs))
+            c2w = torch.as_tensor(np.asarray(render_poses[i]), dtype=torch.float32, device='cpu' if ray_kernel else dev)
+            if not ray_kernel:
+                rays_o, rays_d = get_rays(H, W, Ks[i], c2w, inverse_y=kwargs.get('inverse_y', False), flip_x=flip_x, flip_y=flip_y)
+                viewdirs = rays_d / rays_d.norm(dim=-1, keepdim=True)
+                if ndc:
+                    rays_o, rays_d = ndc_rays(H, W, float(Ks[i][0][0]), 1., rays_o, rays_d)
+            else:
+                rays_o, rays_d, viewdirs = get_rays_of_a_view(H, W, Ks[i], c2w, ndc, inverse_y=kwargs.get('inverse_y', False),
+                                                              flip_x=flip_x, flip_y=flip_y)
+            rays_o, rays_d, viewdirs = (t.flatten(0, -2).contiguous().to(dev) for t in (rays_o, rays_d, viewdirs))
         out_rgb, out_depth = [], []
         n_chunks = n_pix // chunk + 1                              # run.py:91, last chunk may be empty
         for c in range(n_chunks):

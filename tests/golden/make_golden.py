@@ -438,6 +438,38 @@ def gen_trajectory(R):
     save('trajectory', **out)
 
 
+def gen_scale_volume_grid(R):
+    """N4: DirectVoxGO.scale_volume_grid (lib/dvgo.py:228-263) -- trilinear resize of both grids, the new occupancy mask
+    from max_pool3d(activate_density) > fast_color_thres, and the `mask_cache_path` branch (AND with a coarse-stage
+    MaskCache evaluated at the new grid's voxel centres).  Pure PyTorch in the reference except the mask lookup (oracle)."""
+    rng = np.random.default_rng(515)
+    mn, mx = np.array([-1.0, -1.1, -0.9], np.float32), np.array([1.0, 1.2, 1.1], np.float32)
+    out = {'xyz_min': mn, 'xyz_max': mx}
+    # a coarse-stage checkpoint for the mask_cache_path branch
+    cd = (rng.standard_normal((1, 1, 9, 10, 9)) * 5).astype(np.float32)
+    ck = os.path.join(HERE, 'scale_volume_coarse.tar')
+    torch.save({'model_state_dict': {'density': torch.from_numpy(cd)},
+                'model_kwargs': {'act_shift': -13.8155, 'voxel_size_ratio': 1.0, 'xyz_min': mn.tolist(), 'xyz_max': mx.tolist()}}, ck)
+    for tag, path in (('plain', None), ('coarse', ck)):
+        torch.manual_seed(777)
+        m = R.dvgo.DirectVoxGO(mn, mx, num_voxels=12 ** 3, num_voxels_base=24 ** 3, alpha_init=1e-2, fast_color_thres=1e-4,
+                               rgbnet_dim=4, rgbnet_depth=3, rgbnet_width=16, viewbase_pe=4, mask_cache_path=path,
+                               mask_cache_thres=1e-3)
+        with torch.no_grad():
+            ws = tuple(int(v) for v in m.world_size)
+            m.density.copy_(torch.from_numpy(blob_density(ws, mn, mx, rng, amp=22.0, bias=-15.0))[None, None])
+            m.k0.copy_(torch.from_numpy((rng.standard_normal(m.k0.shape) * 0.3).astype(np.float32)))
+        out[f'{tag}_density_in'] = m.density.detach().numpy().copy()
+        out[f'{tag}_k0_in'] = m.k0.detach().numpy().copy()
+        m.scale_volume_grid(20 ** 3)
+        out[f'{tag}_world_size'] = m.world_size.numpy().copy()
+        out[f'{tag}_voxel_size_ratio'] = np.float64(m.voxel_size_ratio)
+        out[f'{tag}_density_out'] = m.density.detach().numpy().copy()
+        out[f'{tag}_k0_out'] = m.k0.detach().numpy().copy()
+        out[f'{tag}_mask_out'] = m.mask_cache.mask.numpy().copy()
+    save('scale_volume_grid', **out)
+
+
 def gen_rays(R):
     """Ray generator pin (lib/ray_utils.py:9-47,80-85 + lib/load_blender.py:37-42)."""
     rng = np.random.default_rng(809)
@@ -457,6 +489,9 @@ def main():
         if len(sys.argv) > 1 and sys.argv[1] == 'checkpoint':
             gen_checkpoint(R)
             return
+        if len(sys.argv) > 1 and sys.argv[1] == 'scale_volume_grid':
+            gen_scale_volume_grid(R)
+            return
         if len(sys.argv) > 1 and sys.argv[1] == 'forward_mpi_w64':
             gen_mpi_forward(R, width=64, name='forward_mpi_w64')
             return
@@ -474,6 +509,7 @@ def main():
         gen_checkpoint(R)
         gen_trajectory(R)
         gen_rays(R)
+        gen_scale_volume_grid(R)
     finally:
         shutil.rmtree(R.scratch, ignore_errors=True)
 

@@ -31,18 +31,23 @@ H = W = args.hw
 K = np.array([[1111.11 * W / 800, 0, 0.5 * W], [0, 1111.11 * H / 800, 0.5 * H], [0, 0, 1]], np.float32)
 poses = [pose_spherical(40.0 * i - 60, -30.0, 4.0).numpy() for i in range(args.views)]
 rk = dict(near=2.0, far=6.0, bg=1, stepsize=0.5, inverse_y=False)
-render_viewpoints(m, poses[:1], [(H, W)], [K], False, rk)            # warm-up
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-rgbs, depths = render_viewpoints(m, poses, [(H, W)] * len(poses), [K] * len(poses), False, rk, chunk=args.chunk)
-torch.cuda.synchronize()
-dt = (time.perf_counter() - t0) / len(poses)
-print(f'grid {args.world}^3 occupancy {sc["occupancy"]:.3f}: {dt * 1e3:.1f} ms per {H}x{W} view ({H * W / dt / 1e6:.2f} M rays/s), '
-      f'mean rgb {rgbs.mean():.3f}, mean depth {depths.mean():.1f}')
+ref = None
+for ray_kernel in (False, True, False, True):          # rays by ~10 torch launches per view (r2) vs one kernel per chunk, interleaved
+    render_viewpoints(m, poses[:1], [(H, W)], [K], False, rk, ray_kernel=ray_kernel)            # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rgbs, depths = render_viewpoints(m, poses, [(H, W)] * len(poses), [K] * len(poses), False, rk, chunk=args.chunk, ray_kernel=ray_kernel)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / len(poses)
+    if ref is None:
+        ref = rgbs
+    print(f'grid {args.world}^3 occupancy {sc["occupancy"]:.3f}, chunk {args.chunk}, rays by {"HIP kernel" if ray_kernel else "torch ops "}: '
+          f'{dt * 1e3:.1f} ms per {H}x{W} view ({H * W / dt / 1e6:.2f} M rays/s), mean rgb {rgbs.mean():.3f}, mean depth {depths.mean():.1f}, '
+          f'max |rgb - first run| {float(np.abs(rgbs - ref).max()):.2e}')
 
 if args.profile:
     from directvoxgo_amd import _lib as L
-    names = ['dvgo_sample_pts_prepare', 'dvgo_march_density', 'dvgo_exclusive_scan_i32', 'dvgo_march_gather',
+    names = ['dvgo_rays_of_view', 'dvgo_sample_pts_prepare', 'dvgo_march_density', 'dvgo_march_scans', 'dvgo_exclusive_scan_i32', 'dvgo_march_gather',
              'dvgo_march_composite', 'dvgo_shade_fwd', 'dvgo_viewdir_embed']
     L.profile_start(names)
     render_viewpoints(m, poses[:1], [(H, W)], [K], False, rk, chunk=args.chunk)
