@@ -35,12 +35,12 @@ extern "C" int dvgo_shade_wgrad_x3(const float* G1, const float* gz, const uint6
                                    int64_t M, const int64_t* m_dev, int width, int diffuse, int n_parts, float* part, void* stream);
 extern "C" int dvgo_shade_bwd_x3(const float* g_rgb, const float* rgb, const uint64_t* masks, int64_t M, const int64_t* m_dev,
                                  const float* W1, const float* W2, const float* W3, int width, int d_in, int C, int diffuse,
-                                 float* g_feat, float* G1, float* gz, void* scratch, void* stream);
+                                 float* g_feat, float* G1, float* gz, void* scratch, int prebuilt, void* stream);
 
 extern "C" int dvgo_shade_fwd_x3(const float* feat, int C, const float* emb, int E, const int64_t* ray_id, int64_t M, const int64_t* m_dev,
                                  const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
                                  const float* b3, int width, int d_in, int diffuse, float* rgb, float* H1, float* H2,
-                                 uint64_t* masks, void* scratch, int experiment, void* stream);
+                                 uint64_t* masks, void* scratch, void* scratch_bwd, int experiment, void* stream);
 
 // Saved activations / gradients are plain row-major [M, features]: in the accumulator layout a lane owns
 // 4 consecutive features per register quad, i.e. one 16-byte piece of its row.
@@ -922,7 +922,7 @@ extern "C" {
 int dvgo_shade_fwd(const float* feat, int C, const float* emb, int E, const int64_t* ray_id, int64_t M, const int64_t* m_dev,
                    const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
                    const float* b3, int width, int d_in, int diffuse, float* rgb, float* H1, float* H2,
-                   uint64_t* masks, void* scratch, void* stream) {
+                   uint64_t* masks, void* scratch, void* scratch_bwd, void* stream) {
   if (M < 0 || C <= 0 || E < 0) return DVGO_EINVAL;
   if (M == 0) return 0;
   if (!feat || !emb || !ray_id || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !rgb) return DVGO_EINVAL;
@@ -933,7 +933,7 @@ int dvgo_shade_fwd(const float* feat, int C, const float* emb, int E, const int6
   if ((width != 128 && width != 64) || d_in > 40) return DVGO_ERANGE;   // outside the instantiated set: caller falls back
   if ((g_shade_variant & 1) && scratch != nullptr)
     return dvgo_shade_fwd_x3(feat, C, emb, E, ray_id, M, m_dev, W1, b1, W2, b2, W3, b3, width, d_in, diffuse, rgb, H1, H2, masks,
-                             scratch, g_shade_experiment, stream);
+                             scratch, (g_shade_variant & 2) ? scratch_bwd : nullptr, g_shade_experiment, stream);
   hipStream_t s = (hipStream_t)stream;
   const int64_t n_tiles = (M + 31) / 32;
   const int64_t cap = width == 128 ? 256 : 512;          // width 128: one workgroup per CU (LDS); width 64: two
@@ -961,7 +961,7 @@ int dvgo_shade_variant(int flags) { const int old = g_shade_variant; if (flags >
 
 int dvgo_shade_bwd(const float* g_rgb, const float* rgb, const uint64_t* masks, int64_t M, const int64_t* m_dev,
                    const float* W1, const float* W2, const float* W3, int width, int d_in, int C, int diffuse,
-                   float* g_feat, float* G1, float* gz, void* scratch, void* stream) {
+                   float* g_feat, float* G1, float* gz, void* scratch, int prebuilt, void* stream) {
   if (M < 0 || C <= 0) return DVGO_EINVAL;
   if (M == 0) return 0;
   if (!g_rgb || !rgb || !masks || !W1 || !W2 || !W3 || !g_feat || !G1 || !gz) return DVGO_EINVAL;
@@ -969,7 +969,7 @@ int dvgo_shade_bwd(const float* g_rgb, const float* rgb, const uint64_t* masks, 
   const int n_view = C - c_view0;
   if ((width != 128 && width != 64) || n_view < 0 || n_view > 32 || d_in < n_view) return DVGO_ERANGE;
   if ((g_shade_variant & 2) && scratch != nullptr)
-    return dvgo_shade_bwd_x3(g_rgb, rgb, masks, M, m_dev, W1, W2, W3, width, d_in, C, diffuse, g_feat, G1, gz, scratch, stream);
+    return dvgo_shade_bwd_x3(g_rgb, rgb, masks, M, m_dev, W1, W2, W3, width, d_in, C, diffuse, g_feat, G1, gz, scratch, prebuilt, stream);
   hipStream_t s = (hipStream_t)stream;
   const int64_t n_tiles = (M + 31) / 32;
   const int64_t cap = width == 128 ? 256 : 512;

@@ -118,13 +118,12 @@ __device__ __forceinline__ void x3_store_tile(float* __restrict__ stage, const f
 }
 
 template <int WIDTH, int KS1>
-__global__ void __launch_bounds__(256)
-x3_prep_fwd_kernel(X3Img<WIDTH, KS1>* __restrict__ Lp, const float* __restrict__ W1, const float* __restrict__ b1,
-                   const float* __restrict__ W2, const float* __restrict__ b2, const float* __restrict__ W3,
-                   const float* __restrict__ b3, int D_in) {
+__device__ __forceinline__ void
+x3_prep_fwd_body(X3Img<WIDTH, KS1>* __restrict__ Lp, const float* __restrict__ W1, const float* __restrict__ b1,
+                 const float* __restrict__ W2, const float* __restrict__ b2, const float* __restrict__ W3,
+                 const float* __restrict__ b3, int D_in, const int tid, const int nt) {
   constexpr int T = WIDTH / 32;
   X3Img<WIDTH, KS1>& L = *Lp;
-  const int tid = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
   for (int i = tid; i < T * KS1 * 64 * 8; i += nt) {
     const int j = i & 7, l = (i >> 3) & 63, s = (i >> 9) % KS1, t = (i >> 9) / KS1;
     const int k = 16 * s + 8 * (l >> 5) + j;
@@ -308,12 +307,11 @@ struct X3BwdLds : X3BwdImg<WIDTH> {
 };
 
 template <int WIDTH>
-__global__ void __launch_bounds__(256)
-x3_prep_bwd_kernel(X3BwdImg<WIDTH>* __restrict__ Lp, const float* __restrict__ W1, const float* __restrict__ W2,
-                   const float* __restrict__ W3, int D_in) {
+__device__ __forceinline__ void
+x3_prep_bwd_body(X3BwdImg<WIDTH>* __restrict__ Lp, const float* __restrict__ W1, const float* __restrict__ W2,
+                 const float* __restrict__ W3, int D_in, const int tid, const int nt) {
   constexpr int T = WIDTH / 32;
   X3BwdImg<WIDTH>& L = *Lp;
-  const int tid = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
   for (int i = tid; i < T * 2 * T * 64 * 8; i += nt) {
     const int j = i & 7, l = (i >> 3) & 63, ks = (i >> 9) % (2 * T), tin = (i >> 9) / (2 * T);
     const int f_out = 16 * ks + 8 * (j >> 2) + 4 * (l >> 5) + (j & 3);
@@ -336,6 +334,24 @@ x3_prep_bwd_kernel(X3BwdImg<WIDTH>* __restrict__ Lp, const float* __restrict__ W
     const int tr = i % (T * 16), h = (i / (T * 16)) & 1, c = i / (2 * T * 16);
     (&L.w3p[0][0][0])[i] = W3[c * WIDTH + x3_acc_feature(tr >> 4, tr & 15, h)];
   }
+}
+
+// One launch builds the weight image of the forward and, for a training step, the image the data-gradient kernel will want
+// (the first 32 workgroups the one, the next 32 the other): the backward then starts without a prep launch of its own.
+template <int WIDTH, int KS1>
+__global__ void __launch_bounds__(256)
+x3_prep_fwd_kernel(X3Img<WIDTH, KS1>* __restrict__ Lp, X3BwdImg<WIDTH>* __restrict__ Lb, const float* __restrict__ W1,
+                   const float* __restrict__ b1, const float* __restrict__ W2, const float* __restrict__ b2,
+                   const float* __restrict__ W3, const float* __restrict__ b3, int D_in) {
+  if (blockIdx.x < 32) x3_prep_fwd_body<WIDTH, KS1>(Lp, W1, b1, W2, b2, W3, b3, D_in, blockIdx.x * blockDim.x + threadIdx.x, 32 * blockDim.x);
+  else x3_prep_bwd_body<WIDTH>(Lb, W1, W2, W3, D_in, (blockIdx.x - 32) * blockDim.x + threadIdx.x, 32 * blockDim.x);
+}
+
+template <int WIDTH>
+__global__ void __launch_bounds__(256)
+x3_prep_bwd_kernel(X3BwdImg<WIDTH>* __restrict__ Lp, const float* __restrict__ W1, const float* __restrict__ W2,
+                   const float* __restrict__ W3, int D_in) {
+  x3_prep_bwd_body<WIDTH>(Lp, W1, W2, W3, D_in, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
 }
 
 template <int WIDTH, bool DIFFUSE>
@@ -683,7 +699,7 @@ int64_t dvgo_shade_scratch_bytes(int width) {
 int dvgo_shade_fwd_x3(const float* feat, int C, const float* emb, int E, const int64_t* ray_id, int64_t M, const int64_t* m_dev,
                       const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
                       const float* b3, int width, int d_in, int diffuse, float* rgb, float* H1, float* H2,
-                      uint64_t* masks, void* scratch, int experiment, void* stream) {
+                      uint64_t* masks, void* scratch, void* scratch_bwd, int experiment, void* stream) {
   if (M < 0 || C <= 0 || E < 0) return DVGO_EINVAL;
   if (M == 0) return 0;
   if (!feat || !emb || !ray_id || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !rgb || !scratch) return DVGO_EINVAL;
@@ -698,7 +714,7 @@ int dvgo_shade_fwd_x3(const float* feat, int C, const float* emb, int E, const i
   const int blocks = (int)((n_tiles + X3_WAVES - 1) / X3_WAVES < cap ? (n_tiles + X3_WAVES - 1) / X3_WAVES : cap);
 #define DVGO_SHADE_X3(W, KS, DIFF)                                                                                       \
   do {                                                                                                                   \
-    x3_prep_fwd_kernel<W, KS><<<32, 256, 0, s>>>((X3Img<W, KS>*)scratch, W1, b1, W2, b2, W3, b3, d_in);                \
+    x3_prep_fwd_kernel<W, KS><<<scratch_bwd ? 64 : 32, 256, 0, s>>>((X3Img<W, KS>*)scratch, (X3BwdImg<W>*)scratch_bwd, W1, b1, W2, b2, W3, b3, d_in); \
     shade_fwd_x3_kernel<W, KS, DIFF><<<blocks, X3_THREADS, 0, s>>>(feat, C, c_view0, n_view, emb, E, ray_id, M, m_dev, scratch, rgb, \
                                                                     H1, H2, (unsigned long long*)masks, experiment);     \
   } while (0)
@@ -715,7 +731,7 @@ int dvgo_shade_fwd_x3(const float* feat, int C, const float* emb, int E, const i
 
 int dvgo_shade_bwd_x3(const float* g_rgb, const float* rgb, const uint64_t* masks, int64_t M, const int64_t* m_dev,
                       const float* W1, const float* W2, const float* W3, int width, int d_in, int C, int diffuse,
-                      float* g_feat, float* G1, float* gz, void* scratch, void* stream) {
+                      float* g_feat, float* G1, float* gz, void* scratch, int prebuilt, void* stream) {
   if (M < 0 || C <= 0) return DVGO_EINVAL;
   if (M == 0) return 0;
   if (!g_rgb || !rgb || !masks || !W1 || !W2 || !W3 || !g_feat || !G1 || !gz || !scratch) return DVGO_EINVAL;
@@ -728,7 +744,7 @@ int dvgo_shade_bwd_x3(const float* g_rgb, const float* rgb, const uint64_t* mask
   const int blocks = (int)((n_tiles + X3_WAVES - 1) / X3_WAVES < cap ? (n_tiles + X3_WAVES - 1) / X3_WAVES : cap);
 #define DVGO_SHADE_BWD_X3(W, DIFF)                                                                                        \
   do {                                                                                                                    \
-    x3_prep_bwd_kernel<W><<<32, 256, 0, s>>>((X3BwdImg<W>*)scratch, W1, W2, W3, d_in);                                  \
+    if (!prebuilt) x3_prep_bwd_kernel<W><<<32, 256, 0, s>>>((X3BwdImg<W>*)scratch, W1, W2, W3, d_in);                   \
     shade_bwd_x3_kernel<W, DIFF><<<blocks, X3_THREADS, 0, s>>>(g_rgb, rgb, (const unsigned long long*)masks, M, m_dev, scratch, C, \
                                                                 c_view0, n_view, g_feat, G1, gz);                         \
   } while (0)

@@ -122,16 +122,20 @@ class _Shade(torch.autograd.Function):
         H2 = torch.empty((M, width), dtype=torch.float32, device=feat.device) if train else None
         masks = torch.empty((M, 4), dtype=torch.int64, device=feat.device) if train else None
         scratch = _scratch(width, feat.device)
+        # training: the weight image of the data-gradient kernel is built by the forward's prep launch (one launch less)
+        scratch_bwd = _scratch(width, feat.device) if (train and (L.lib().dvgo_shade_variant(-1) & 2)) else None
         with L.device_of(feat):
             L.call('dvgo_shade_fwd', ptr(feat), _int(C), ptr(emb), _int(E), ptr(ray_id), _i64(M), ptr(m_dev), ptr(W1.contiguous()),
                    ptr(b1.contiguous()), ptr(W2.contiguous()), ptr(b2.contiguous()), ptr(W3.contiguous()),
                    ptr(b3.contiguous()), _int(width), _int(d_in), _int(1 if diffuse else 0), ptr(rgb), ptr(H1), ptr(H2),
-                   ptr(masks), ptr(scratch), stream_of(feat))
+                   ptr(masks), ptr(scratch), ptr(scratch_bwd), stream_of(feat))
+        ctx.scratch_bwd = scratch_bwd if (train and (L.lib().dvgo_shade_variant(-1) & 1)) else None     # (built only by the x3 forward)
         if train:
             ctx.save_for_backward(feat, emb, ray_id, W1, W2, W3, rgb, H1, H2, masks)
             ctx.diffuse = diffuse
             ctx.m_dev = m_dev            # None, or the device-side sample count (arrays are then capacity-sized)
             ctx.params = (W1, b1, W2, b2, W3, b3)
+            ctx.w_versions = (W1._version, W2._version, W3._version)
         return rgb
 
     @staticmethod
@@ -144,11 +148,14 @@ class _Shade(torch.autograd.Function):
         g_feat = torch.empty_like(feat)
         G1 = torch.empty_like(H1)
         gz = torch.empty_like(rgb)
-        scratch = _scratch(width, feat.device)
+        prebuilt = ctx.scratch_bwd is not None and W1._version == ctx.w_versions[0] and W2._version == ctx.w_versions[1] \
+            and W3._version == ctx.w_versions[2]                 # (weights untouched since the forward built the image)
+        scratch = ctx.scratch_bwd if prebuilt else _scratch(width, feat.device)
+        ctx.scratch_bwd = None
         with L.device_of(feat):
             L.call('dvgo_shade_bwd', ptr(g_rgb.contiguous()), ptr(rgb), ptr(masks), _i64(M), ptr(m_dev), ptr(W1.contiguous()),
                    ptr(W2.contiguous()), ptr(W3.contiguous()), _int(width), _int(d_in), _int(C), _int(1 if diffuse else 0),
-                   ptr(g_feat), ptr(G1), ptr(gz), ptr(scratch), stream_of(feat))
+                   ptr(g_feat), ptr(G1), ptr(gz), ptr(scratch), _int(1 if prebuilt else 0), stream_of(feat))
 
         def wgrad():
             n_parts = max(1, min(N_PARTS, (M + 255) // 256))      # >= 8 row tiles per workgroup on small batches

@@ -418,8 +418,18 @@ class TrainStep:
         return True
 
     def _replay(self, rays_o, rays_d, viewdirs, target):
-        for dst, src in zip(self._static, (rays_o, rays_d, viewdirs, target)):
-            dst.copy_(src, non_blocking=True)
+        srcs = (rays_o, rays_d, viewdirs, target)
+        if all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.shape == d.shape for t, d in zip(srcs, self._static)):
+            import ctypes
+            from . import _lib as L
+            n = len(srcs)                                   # the four inputs in one launch (csrc/loss.hip copy_multi)
+            with L.device_of(rays_o):
+                L.call('dvgo_copy_multi', (ctypes.c_void_p * n)(*[d.data_ptr() for d in self._static]),
+                       (ctypes.c_void_p * n)(*[t.data_ptr() for t in srcs]), (ctypes.c_int64 * n)(*[t.numel() for t in srcs]),
+                       ctypes.c_int(n), L.stream_of(rays_o))
+        else:
+            for dst, src in zip(self._static, srcs):
+                dst.copy_(src, non_blocking=True)
         self.optimizer.hyper_begin(self.model.density, self.model.k0, advance=True)    # this step's Adam step sizes
         self._graph.replay()
         for group in self.optimizer.param_groups:                                                  # run.py:401-406

@@ -399,7 +399,10 @@ int dvgo_shade_fwd(const float* feat, int C, const float* emb, int E, const int6
                    const float* W1, const float* b1, const float* W2, const float* b2,
                    const float* W3, const float* b3, int width, int d_in, int diffuse,
                    float* rgb, float* H1, float* H2, uint64_t* masks,
-                   void* scratch /* NULL, or dvgo_shade_scratch_bytes(width) bytes of device memory */, void* stream);
+                   void* scratch /* NULL, or dvgo_shade_scratch_bytes(width) bytes of device memory */,
+                   void* scratch_bwd /* NULL, or a second block of that size: a training step has the weight image of the
+                                        data-gradient kernel built by the same prep launch (dvgo_shade_bwd: prebuilt = 1) */,
+                   void* stream);
 
 /* Kernel variants of the colour head (process-global, for A/B runs; returns the previous value, negative = query):
  *   bit 0  forward, bit 1 data gradients on the bf16 matrix cores: every fp32 operand split EXACTLY into three bf16
@@ -417,7 +420,9 @@ int dvgo_shade_variant(int flags);
  * channels [0,3) = gz when diffuse, channels [c0, C) = (W1^T G1)[:C-c0]. */
 int dvgo_shade_bwd(const float* g_rgb, const float* rgb, const uint64_t* masks, int64_t M, const int64_t* m_dev,
                    const float* W1, const float* W2, const float* W3, int width, int d_in, int C, int diffuse,
-                   float* g_feat, float* G1, float* gz, void* scratch, void* stream);
+                   float* g_feat, float* G1, float* gz, void* scratch,
+                   int prebuilt /* scratch already holds this kernel's weight image (dvgo_shade_fwd: scratch_bwd) */,
+                   void* stream);
 
 /* Weight-gradient part (G1, gz from dvgo_shade_bwd; masks, H1, H2 from dvgo_shade_fwd; W3 as given to both):
  * dW2 = G2^T H1, dW1 = G1^T X (X = the layer-1 input, re-assembled from feat / emb /
@@ -481,6 +486,9 @@ int dvgo_loss_fwd_bwd(const float* rgb_marched, const float* alphainv_last, cons
                       const float* raw_rgb, const float* weights, const int64_t* ray_id, int64_t M, const int64_t* m_dev,
                       int64_t n_rays_global, float w_main, float w_ent, float w_per,
                       float* g_marched, float* g_last, float* g_raw_rgb, float* loss_out, void* stream);
+/* dvgo_copy_multi: dst[k][0 .. n_dwords[k]) = src[k][...] for up to 8 (dst, src) pairs of 4-byte elements in ONE launch
+ * (harness plumbing: the batch of a captured training step is copied into the graph's input tensors). */
+int dvgo_copy_multi(void* const* dst, const void* const* src, const int64_t* n_dwords, int n_tensors, void* stream);
 int dvgo_viewdir_embed(const float* viewdirs, const float* freq, int n_freq, int64_t N, float* emb, void* stream);
 int dvgo_adam_upd_multi(float* const* params, const float* const* grads, float* const* exp_avg,
                         float* const* exp_avg_sq, const int64_t* numel, int n_tensors, float step_size,
