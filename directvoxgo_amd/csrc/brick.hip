@@ -36,7 +36,11 @@ march_scans_kernel(const int32_t* __restrict__ n3, int n_rays, int64_t* __restri
                    int32_t* __restrict__ brick_cursor, int32_t* __restrict__ extra, int32_t* __restrict__ active,
                    int32_t* __restrict__ extra_brick, int n_extra_max, int slice_len) {
   if (blockIdx.x == 0) block_scan_i32<16, int64_t>(n_rays, off3, [&](int i) { return n3[i]; });
-  else brick_tables<16, false>(brick_cnt, nb, brick_off, brick_cursor, extra, active, extra_brick, n_extra_max, slice_len);
+  else {
+    brick_tables<16, false>(brick_cnt, nb, brick_off, brick_cursor, extra, active, extra_brick, n_extra_max, slice_len);
+    // the list total next to the sample total: the forward's one host read is then 16 contiguous bytes, no gather launch
+    if (threadIdx.x == 0) off3[n_rays + 1] = (int64_t)brick_off[nb];
+  }
 }
 
 struct BrickAdam {

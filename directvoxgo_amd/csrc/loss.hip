@@ -59,7 +59,8 @@ loss_samples_kernel(const float* __restrict__ raw_rgb, const float* __restrict__
   __shared__ float red[4];
   float l = 0.0f;
   // grid-stride: one same-address atomic per workgroup is the cost that matters here (~12 ns each, serialised: 1024
-  // workgroups cost 13 us on a 0.2 M-sample step), so at most 256 long-lived workgroups
+  // workgroups cost 13 us on a 0.2 M-sample step), so at most 256 long-lived workgroups (1024 from 1 M rows up, where the
+  // stream itself wants the parallelism)
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = ray_id[i];
     const float w = weights[i];
@@ -179,7 +180,7 @@ int dvgo_loss_fwd_bwd(const float* rgb_marched, const float* alphainv_last, cons
   if (M > 0 && w_per > 0.0f) {
     if (!raw_rgb || !weights || !ray_id || !g_raw_rgb) return DVGO_EINVAL;
     const int64_t nb = dvgo_blocks(M, 256);
-    loss_samples_kernel<<<(int)(nb < 256 ? nb : 256), 256, 0, s>>>(raw_rgb, weights, ray_id, target, M, m_dev, inv, w_per,
+    loss_samples_kernel<<<(int)(nb < 256 ? nb : (M >= (1 << 20) ? 1024 : 256)), 256, 0, s>>>(raw_rgb, weights, ray_id, target, M, m_dev, inv, w_per,
                                                             g_raw_rgb, loss_out);
     DVGO_LAUNCH_CHECK();
   }

@@ -375,8 +375,11 @@ march_density_kernel(float* __restrict__ rays_start, float* __restrict__ rays_di
   if (!s_is_last) return;
   block_scan_i32_sc1<DVGO_BLOCK / 64, int64_t>(n3, (int)n_rays, tail.off3);
   if (brick_cnt != nullptr && tail.brick_off != nullptr)
+  {
     brick_tables<DVGO_BLOCK / 64, true>(brick_cnt, tail.nb, tail.brick_off, tail.brick_cursor, tail.extra, tail.active,
                                         tail.extra_brick, tail.n_extra_max, tail.slice_len);
+    if (threadIdx.x == 0) tail.off3[n_rays + 1] = (int64_t)tail.brick_off[tail.nb];      // (as dvgo_march_scans)
+  }
   if (threadIdx.x == 0) __hip_atomic_store(tail.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 

@@ -180,7 +180,7 @@ class _FusedMarch(torch.autograd.Function):
         n2 = torch.empty(N, dtype=torch.int32, device=dev)
         n3 = torch.empty(N, dtype=torch.int32, device=dev)
         last = torch.empty(N, dtype=torch.float32, device=dev)
-        off3 = torch.empty(N + 1, dtype=torch.int64, device=dev)
+        off3 = torch.empty(N + 2, dtype=torch.int64, device=dev)     # [N]: surviving samples, [N + 1]: brick-list entries
         with L.device_of(rays_o):
             if not ndc and not setup_in_march:
                 t_min = torch.empty(N, dtype=torch.float32, device=dev)
@@ -260,13 +260,19 @@ class _FusedMarch(torch.autograd.Function):
                 M3 = stride * N
                 n_entries = 8 * M3                              # a sample touches at most 2 x 2 x 2 bricks
             elif bricks and bu is not None:
-                M3, n_entries, n_union = torch.stack((off3[-1], brick_off[0, -1].long(), union_tabs[3, -1].long())).tolist()
+                if N > 16384:
+                    off3[N + 1] = brick_off[0, -1]
+                off3 = torch.cat((off3, union_tabs[3, -1:].long()))           # (data parallel: the union size rides along)
+                M3, n_entries, n_union = off3[N:N + 3].tolist()
+                off3 = off3[:N + 2]
                 bu.n_union, bu.n_bricks = n_union, nb
                 bu.sparse = n_union <= bu.max_frac * nb
             elif bricks:
-                M3, n_entries = torch.stack((off3[-1], brick_off[0, -1].long())).tolist()   # the one host sync
+                if N > 16384:                                   # (the multi-workgroup scan path does not write the list total)
+                    off3[N + 1] = brick_off[0, -1]
+                M3, n_entries = off3[N:N + 2].tolist()          # the one host sync: 16 contiguous bytes, no gather launch
             else:
-                M3 = int(off3[-1].item())                      # the one host sync of the fused forward
+                M3 = int(off3[N].item())                       # the one host sync of the fused forward
             ray_id = torch.empty(M3, dtype=torch.int64, device=dev)
             step_id = torch.empty(M3, dtype=torch.int64, device=dev)
             weights = torch.empty(M3, dtype=torch.float32, device=dev)
@@ -284,6 +290,7 @@ class _FusedMarch(torch.autograd.Function):
         ctx.density_meta, ctx.k0_meta = density, k0
         ctx.save_for_backward(rec2, n2, n_steps, cum if cum is not None else n_steps, off3, start, dirs, last,
                               ray_id, step_id)
+        off3 = off3[:N + 1]
         ctx.mark_non_differentiable(alpha, ray_id, step_id, off3)
         ctx.set_materialize_grads(False)     # no zero-filled [M3] int64 'gradients' for the id outputs (33 MB per step)
         return weights, alpha, last, feat, ray_id, step_id, off3

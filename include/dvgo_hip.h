@@ -327,7 +327,9 @@ int dvgo_brick_slice(void);     /* default slice_len: entries per work item of d
  *   - brick_cnt is CLEARED: it becomes the arrival counter array of the slices. */
 int dvgo_brick_scan(int32_t* brick_cnt, int n_bricks, int32_t* brick_off, int32_t* brick_cursor, int32_t* extra_off,
                     int32_t* active, int32_t* extra_brick /* [n_extra_max] */, int n_extra_max, int slice_len, void* stream);
-/* the ray scan (n3 [n_rays] -> off3 [n_rays + 1], int64) and dvgo_brick_scan in one launch; brick_cnt == NULL: rays only */
+/* the ray scan (n3 [n_rays] -> off3 [n_rays + 1], int64) and dvgo_brick_scan in one launch; brick_cnt == NULL: rays only.
+ * With bricks, off3 must have n_rays + 2 entries: off3[n_rays + 1] = brick_off[n_bricks], the total list length, so that the
+ * caller's one host read (sample total, list total) is 16 contiguous bytes. */
 int dvgo_march_scans(const int32_t* n3, int64_t n_rays, int64_t* off3, int32_t* brick_cnt, int n_bricks,
                      int32_t* brick_off, int32_t* brick_cursor, int32_t* extra_off, int32_t* active, int32_t* extra_brick,
                      int n_extra_max, int slice_len, void* stream);
