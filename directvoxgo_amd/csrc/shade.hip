@@ -32,7 +32,8 @@ static int g_shade_experiment = 0;   // timing experiments only (tools/): bit 0 
 static int g_shade_variant = 3;
 extern "C" int dvgo_shade_wgrad_x3(const float* G1, const float* gz, const uint64_t* masks, const float* W3, const float* H1,
                                    const float* H2, const float* feat, int C, const float* emb, int E, const int64_t* ray_id,
-                                   int64_t M, const int64_t* m_dev, int width, int diffuse, int n_parts, float* part, void* stream);
+                                   int64_t M, const int64_t* m_dev, int width, int diffuse, int n_parts, float* part, int form_b,
+                                   void* stream);
 extern "C" int dvgo_shade_bwd_x3(const float* g_rgb, const float* rgb, const uint64_t* masks, int64_t M, const int64_t* m_dev,
                                  const float* W1, const float* W2, const float* W3, int width, int d_in, int C, int diffuse,
                                  float* g_feat, float* G1, float* gz, void* scratch, int prebuilt, void* stream);
@@ -994,8 +995,10 @@ int dvgo_shade_wgrad(const float* G1, const float* gz, const uint64_t* masks, co
   if ((width != 128 && width != 64) || n_view < 0 || n_view + E > 40) return DVGO_ERANGE;
   bool ring = false;                        // (the pipelined kernel zeroes `total` itself: one launch less)
   if (g_shade_variant & 4) {
-    if (n_parts > 256) n_parts = 256;       // one 8-wave workgroup per CU (141 KB of LDS)
-    const int rc = dvgo_shade_wgrad_x3(G1, gz, masks, W3, H1, H2, feat, C, emb, E, ray_id, M, m_dev, width, diffuse, n_parts, part, stream);
+    const int form_b = (g_shade_variant & 16) ? 1 : 0;      // 4-wave workgroups, two per CU (68 KB of LDS each)
+    if (!form_b && n_parts > 256) n_parts = 256;           // else: one 8-wave workgroup per CU (141 KB of LDS)
+    const int rc = dvgo_shade_wgrad_x3(G1, gz, masks, W3, H1, H2, feat, C, emb, E, ray_id, M, m_dev, width, diffuse, n_parts, part,
+                                       form_b, stream);
     if (rc != 0) return rc;
   } else if (!(g_shade_variant & 8) && n_view <= 16 && E <= 32 && (n_view + E <= 32 || (n_view % 4 == 0 && n_view >= 8)) &&
              M * width * 4 < ((int64_t)1 << 31) && M * C * 4 < ((int64_t)1 << 31)) {

@@ -687,6 +687,201 @@ shade_wgrad_x3_kernel(const float* __restrict__ G1, const float* __restrict__ gz
     if (q >= 16 || (q & 7) >= 3) pb[2 * WIDTH + q] = 0.0f;
 }
 
+// ----------------------------------------------------------------------------------
+// Weight gradients on the split operands, second form (round 3; dvgo_shade_variant bit 4 picks it over the one above).
+// Same arithmetic, same `part` record; what changes is who waits for whom.  The first form is one 8-wave workgroup per CU
+// (141 KB of LDS: double-buffered operand tiles) whose waves meet at two barriers per 32-row tile with ~2,800 cycles of work
+// in between -- less than a DMA round trip -- and it ends at the time of the f32-MFMA kernel although it issues a third of
+// its matrix cycles.  Here a workgroup is T = 4 waves, wave w owns out-feature tile w for BOTH k-steps (no exchange of
+// partial tiles at the end), the operand tiles are single-buffered (G1, H1; H2 is only needed column-wise for dW3 and is
+// read straight from global memory), which leaves 68 KB of LDS per workgroup: TWO workgroups per CU, each covering the
+// other's DMA round trip and barriers.
+// ----------------------------------------------------------------------------------
+template <int WIDTH>
+struct X3WgradLdsB {
+  static constexpr int T = WIDTH / 32;
+  float g1[32][WIDTH], h1[32][WIDTH];
+  float x[32][40];
+  float gz[32][4];
+  unsigned int m2[32][2][2];               // layer-2 sign bits [row][lane half of the forward][32-bit half]
+  u32x4 fb[T + 1][2][3][64];               // shared B fragments: [in tile (T = the X tile)][k-step][piece][lane]
+};
+
+template <int WIDTH>
+__global__ void __launch_bounds__(WIDTH * 2, 2)       // T waves; two workgroups per CU
+shade_wgrad_x3b_kernel(const float* __restrict__ G1, const float* __restrict__ gz, const unsigned int* __restrict__ masks,
+                       const float* __restrict__ W3, const float* __restrict__ H1, const float* __restrict__ H2,
+                       const float* __restrict__ feat, int C, int c_view0, int n_view, const float* __restrict__ emb, int E,
+                       const int64_t* __restrict__ ray_id, int64_t M_cap, const int64_t* __restrict__ m_dev,
+                       float* __restrict__ part /* [gridDim][WIDTH*WIDTH + WIDTH*64 + 32*WIDTH + 3*WIDTH] */) {
+  const int64_t M = m_dev ? (*m_dev < M_cap ? *m_dev : M_cap) : M_cap;      // sample count kept on the device (train.py)
+  constexpr int T = WIDTH / 32;
+  constexpr int NW = T;                      // waves
+  constexpr int NT = NW * 64;                // threads
+  constexpr int TPR = NT / 32;               // staging threads per X row
+  constexpr int NXI = (40 + TPR - 1) / TPR;  // X columns per staging thread
+  constexpr int LPR = WIDTH / 4;             // lanes per operand row in a DMA instruction (16 B per lane)
+  constexpr int RPI = 64 / LPR;              // rows per DMA wave instruction (1 KB)
+  constexpr int IPW = 32 / RPI / NW;         // DMA instructions per wave and operand
+  __shared__ __attribute__((aligned(16))) X3WgradLdsB<WIDTH> L;
+  static_assert(sizeof(X3WgradLdsB<WIDTH>) <= 80 * 1024, "two workgroups per CU");
+  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, i = lane & 31, w = tid >> 6;
+  const int ot = w;
+  f32x16 aW2[T], aW1;
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) aW2[t][r] = 0.0f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) aW1[r] = 0.0f;
+  float vW3[3] = {0.0f, 0.0f, 0.0f}, vW1[8];
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) vW1[kk] = 0.0f;
+  float sb1 = 0.0f, sb2 = 0.0f, gz_acc = 0.0f;
+  const float w30 = W3[32 * ot + i], w31 = W3[WIDTH + 32 * ot + i], w32 = W3[2 * WIDTH + 32 * ot + i];
+  const int m_half = (i >> 2) & 1, m_word = ot >> 1, m_bit = 16 * (ot & 1) + (i & 3) + 4 * (i >> 3);
+  const int d_in = n_view + E;
+  const int64_t n_tiles = (M + 31) / 32;
+  const int xrow = tid / TPR, xcol = tid - xrow * TPR;
+
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t r0 = tile * 32;
+    // ---- this tile's operands: G1 / H1 by LDS-DMA, the small ones through registers
+#pragma unroll
+    for (int q = 0; q < IPW; ++q) {
+      const int rl = (IPW * w + q) * RPI;
+      const int64_t row = r0 + rl + lane / LPR;
+      const int64_t off = (row < M ? row : M - 1) * WIDTH + 4 * (lane % LPR);
+      __builtin_amdgcn_global_load_lds((x3_gptr_t)(G1 + off), (x3_lptr_t)&L.g1[rl][0], 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((x3_gptr_t)(H1 + off), (x3_lptr_t)&L.h1[rl][0], 16, 0, 0);
+    }
+    {
+      const int64_t row = r0 + xrow;
+      const int64_t rc = row < M ? row : M - 1;
+      const float* fr = feat + rc * C + c_view0;
+      const float* er = emb + ray_id[rc] * E - n_view;
+#pragma unroll
+      for (int q = 0; q < NXI; ++q) {
+        const int k = xcol + TPR * q;
+        const int kc = k < d_in ? k : d_in - 1;
+        const float v = *((kc < n_view) ? fr + kc : er + kc);
+        if (k < 40) L.x[xrow][k] = (row < M && k < d_in) ? v : 0.0f;
+      }
+    }
+    if (tid < 128) {
+      const int64_t row = r0 + (tid >> 2);
+      const int64_t rc = row < M ? row : M - 1;
+      const bool ok = (tid & 3) < 3 && row < M;
+      const float g = gz[rc * 3 + ((tid & 3) < 3 ? (tid & 3) : 0)];
+      gz_acc += ok ? g : 0.0f;                            // db3[c] = sum of gz[:, c]
+      L.gz[tid >> 2][tid & 3] = ok ? g : 0.0f;
+      (&L.m2[tid >> 2][0][0])[tid & 3] = masks[rc * 8 + 4 + (tid & 3)];
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's share of the DMA has landed
+    __syncthreads();
+    const int rows_valid = (int)(M - r0 < 32 ? M - r0 : 32);  // wave-uniform
+    // ---- shared B fragments: wave w builds H1's in tile w for both k-steps; waves 0 / 1 also the X tile's
+    {
+      u32x4 p0, p1, p2;
+      float v[8];
+#pragma unroll
+      for (int bs = 0; bs < 2; ++bs) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = L.h1[16 * bs + 8 * h + e][32 * w + i];      // rows past M: multiplied by a zero A
+        x3_split8(v, p0, p1, p2);
+        L.fb[w][bs][0][lane] = p0; L.fb[w][bs][1][lane] = p1; L.fb[w][bs][2][lane] = p2;
+      }
+      if (w < 2) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = L.x[16 * w + 8 * h + e][i];
+        x3_split8(v, p0, p1, p2);
+        L.fb[T][w][0][lane] = p0; L.fb[T][w][1][lane] = p1; L.fb[T][w][2][lane] = p2;
+      }
+    }
+    __syncthreads();                        // the B fragments are complete
+#pragma unroll 1
+    for (int ks = 0; ks < 2; ++ks) {
+      // ---- this wave's A fragments of k-step ks: G2 rebuilt from gz and the sign bits, G1 from the tile; fp32 tails
+      u32x4 a2f[3], a1f[3];
+      {
+        float hv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {          // H2 column of this lane's out feature: straight from global memory
+          const int64_t row = r0 + 16 * ks + 8 * h + e;
+          hv[e] = H2[(row < M ? row : M - 1) * WIDTH + 32 * ot + i];
+        }
+        float a2[8], a1[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int row = 16 * ks + 8 * h + e;
+          const float4 gzr = *reinterpret_cast<const float4*>(&L.gz[row][0]);     // 0 on rows past M
+          const float g2v = fmaf(w32, gzr.z, fmaf(w31, gzr.y, w30 * gzr.x));
+          a2[e] = ((L.m2[row][m_half][m_word] >> m_bit) & 1u) ? g2v : 0.0f;
+          a1[e] = row < rows_valid ? L.g1[row][32 * ot + i] : 0.0f;            // rows past M hold a clamped copy
+          sb2 += a2[e]; sb1 += a1[e];
+          vW3[0] = fmaf(gzr.x, hv[e], vW3[0]); vW3[1] = fmaf(gzr.y, hv[e], vW3[1]); vW3[2] = fmaf(gzr.z, hv[e], vW3[2]);
+          const float4 xa = *reinterpret_cast<const float4*>(&L.x[row][32]);     // zero past d_in
+          const float4 xb = *reinterpret_cast<const float4*>(&L.x[row][36]);
+          vW1[0] = fmaf(a1[e], xa.x, vW1[0]); vW1[1] = fmaf(a1[e], xa.y, vW1[1]); vW1[2] = fmaf(a1[e], xa.z, vW1[2]);
+          vW1[3] = fmaf(a1[e], xa.w, vW1[3]); vW1[4] = fmaf(a1[e], xb.x, vW1[4]); vW1[5] = fmaf(a1[e], xb.y, vW1[5]);
+          vW1[6] = fmaf(a1[e], xb.z, vW1[6]); vW1[7] = fmaf(a1[e], xb.w, vW1[7]);
+          if (e & 1) __builtin_amdgcn_sched_barrier(0);     // two rows' worth of LDS reads in flight, not all eight
+        }
+        x3_split8(a2, a2f[0], a2f[1], a2f[2]);
+        x3_split8(a1, a1f[0], a1f[1], a1f[2]);
+      }
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        x3_mfma6(aW2[t], a2f[0], a2f[1], a2f[2], L.fb[t][ks][0][lane], L.fb[t][ks][1][lane], L.fb[t][ks][2][lane]);
+        __builtin_amdgcn_sched_barrier(0);      // one fragment triple in registers at a time
+      }
+      x3_mfma6(aW1, a1f[0], a1f[1], a1f[2], L.fb[T][ks][0][lane], L.fb[T][ks][1][lane], L.fb[T][ks][2][lane]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();                        // every read of this tile's LDS is done: the next tile may land
+  }
+  // ---- the record (layout of the first form: the reduce kernel and the host code are shared)
+  float* p = part + (int64_t)blockIdx.x * (WIDTH * WIDTH + WIDTH * 64 + 32 * WIDTH + 3 * WIDTH);
+  float* pW2 = p;                          // [WIDTH out][WIDTH in]
+  float* pW1 = pW2 + WIDTH * WIDTH;        // [WIDTH out][64]
+  float* pW3 = pW1 + WIDTH * 64;           // [32 (c padded)][WIDTH], rows 0..2 written
+  float* pb = pW3 + 32 * WIDTH;            // [3][WIDTH]: db1, db2, db3 (entries [0,3) + [8,11))
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int oi = (r & 3) + 8 * (r >> 2) + 4 * h;       // D[row = out feature oi][col = in feature i]
+#pragma unroll
+    for (int t = 0; t < T; ++t) pW2[(32 * ot + oi) * WIDTH + 32 * t + i] = aW2[t][r];
+    pW1[(32 * ot + oi) * 64 + i] = aW1[r];
+  }
+  // VALU parts: this lane's out feature is 32 ot + i; the two lane halves hold different rows
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) {
+    float v = vW1[kk];
+    v += __shfl_xor(v, 32);
+    if (h == 0) pW1[(32 * ot + i) * 64 + 32 + kk] = v;
+  }
+  if (h == 0) {
+#pragma unroll
+    for (int kk = 8; kk < 32; ++kk) pW1[(32 * ot + i) * 64 + 32 + kk] = 0.0f;
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float v = vW3[c];
+    v += __shfl_xor(v, 32);
+    if (h == 0) pW3[c * WIDTH + 32 * ot + i] = v;
+  }
+  float s1 = sb1, s2 = sb2;
+  s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+  if (h == 0) { pb[32 * ot + i] = s1; pb[WIDTH + 32 * ot + i] = s2; }
+  // db3[c]: the staging threads 4*row + c (tid < 128: waves 0 and 1) hold per-row sums; fold the row bits of the lane
+  float gz_sum = gz_acc;
+  gz_sum += __shfl_xor(gz_sum, 4); gz_sum += __shfl_xor(gz_sum, 8);
+  gz_sum += __shfl_xor(gz_sum, 16); gz_sum += __shfl_xor(gz_sum, 32);
+  if (w < 2 && lane < 3) pb[2 * WIDTH + 8 * w + lane] = gz_sum;
+  for (int q = tid; q < WIDTH; q += NT)
+    if (q >= 16 || (q & 7) >= 3) pb[2 * WIDTH + q] = 0.0f;
+}
+
 extern "C" {
 
 // bytes of scratch the bf16 variants need per call (the weight image of the larger of the two kernels)
@@ -757,13 +952,19 @@ int dvgo_shade_bwd_x3(const float* g_rgb, const float* rgb, const uint64_t* mask
 
 int dvgo_shade_wgrad_x3(const float* G1, const float* gz, const uint64_t* masks, const float* W3, const float* H1,
                         const float* H2, const float* feat, int C, const float* emb, int E, const int64_t* ray_id, int64_t M,
-                        const int64_t* m_dev, int width, int diffuse, int n_parts, float* part, void* stream) {
+                        const int64_t* m_dev, int width, int diffuse, int n_parts, float* part, int form_b, void* stream) {
   if (M < 0 || n_parts <= 0 || C <= 0 || E < 0) return DVGO_EINVAL;
   if (!G1 || !gz || !masks || !W3 || !H1 || !H2 || !feat || !emb || !ray_id || !part) return DVGO_EINVAL;
   const int c_view0 = diffuse ? 3 : 0;
   const int n_view = C - c_view0;
   if ((width != 128 && width != 64) || n_view < 0 || n_view + E > 40) return DVGO_ERANGE;
-  if (width == 128)
+  if (form_b && width == 128)
+    shade_wgrad_x3b_kernel<128><<<n_parts, 256, 0, (hipStream_t)stream>>>(G1, gz, (const unsigned int*)masks, W3, H1, H2, feat, C,
+                                                                          c_view0, n_view, emb, E, ray_id, M, m_dev, part);
+  else if (form_b)
+    shade_wgrad_x3b_kernel<64><<<n_parts, 128, 0, (hipStream_t)stream>>>(G1, gz, (const unsigned int*)masks, W3, H1, H2, feat, C,
+                                                                         c_view0, n_view, emb, E, ray_id, M, m_dev, part);
+  else if (width == 128)
     shade_wgrad_x3_kernel<128><<<n_parts, 512, 0, (hipStream_t)stream>>>(G1, gz, (const unsigned int*)masks, W3, H1, H2, feat, C,
                                                                          c_view0, n_view, emb, E, ray_id, M, m_dev, part);
   else

@@ -326,7 +326,7 @@ def test_scans_short_and_long(n):
     (40000, False, 128, 12, 27),                       # the rgbnet_direct head of configs/default.py (d_in 39)
     (33, False, 64, 9, 3), (50001, False, 64, 9, 3),   # the LLFF head (configs/llff, lib/dmpigo.py): width 64, d_in 12
     (3000, True, 64, 12, 27), (3000, False, 128, 9, 3)])
-@pytest.mark.parametrize('variant', [0, 7])
+@pytest.mark.parametrize('variant', [0, 7, 23])
 def test_shade_matches_torch_modules(M, diffuse, width, C, E, variant):
     """The colour head kernels vs the torch modules they replace (lib/dvgo.py:516-541), values and grads: csrc/shade.hip
     (fp32 MFMA, variant 0) and csrc/shade_x3.hip (bf16 matrix cores on exactly 3-way-split fp32 operands) -- the SAME
