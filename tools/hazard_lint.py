@@ -13,6 +13,10 @@ Rules (LLVM GCNHazardRecognizer, gfx90a / gfx940 families; wait states = instruc
   R4  VALU writes an SGPR/VCC -> v_readlane / v_writelane lane select         >= 4
   R5  VALU writes an SGPR     -> VMEM instruction reads it (address)          >= 5
   R6  VALU writes VCC         -> v_div_fmas                                   >= 4
+  R7  no packed-fp32 VALU (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32) at all: not a wait-state rule but an empirical one.  hipcc's
+      SLP vectoriser packs adjacent scalar fp32 operations into them; on gfx950 (ROCm 7.2) two kernels of this repository gave
+      results that changed from run to run -- one half of a packed result lost -- until they were compiled without
+      (-fno-slp-vectorize, directvoxgo_amd/build.py; profiles/r3/packed_f32.md has both reproductions).
 Distances are taken over every path (branch targets and fall-through), looking back across loop back-edges.
 
   python tools/hazard_lint.py file.s [--kernel substr] [--report]      exit status 1 when a rule is violated
@@ -216,6 +220,8 @@ def check_kernel(name, items, report=False):
             rule('R5 VALU-written SGPR read by VMEM', {r for r in x.src if r[0] == 's'}, 5)
         if x.mn.startswith('v_div_fmas'):
             rule('R6 VALU-written VCC read by v_div_fmas', {('vcc', 0)}, 4)
+        if x.mn.startswith(('v_pk_add_f32', 'v_pk_mul_f32', 'v_pk_fma_f32')):
+            bad.append(f'{name}: line {x.line}: R7 packed-fp32 VALU instruction (build with -fno-slp-vectorize):  {x.text}')
     return bad, hist
 
 

@@ -12,22 +12,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 SO = os.path.join(CSRC, 'libdvgo_hip.so')
 SOURCES = ['sampling.hip', 'pointwise.hip', 'composite.hip', 'grid_sample.hip', 'march.hip', 'optim.hip', 'shade.hip', 'shade_x3.hip', 'loss.hip', 'brick.hip', 'maintain.hip']
-HEADERS = ['common.h', 'scan.h', 'x3.h', os.path.join('..', '..', 'include', 'dvgo_hip.h')]
+HEADERS = ['common.h', os.path.join('..', '..', 'include', 'dvgo_hip.h')]
 
 # -ffp-contract=off : a*b+c is fused only where the source says fmaf(), so that index and
 #                     position arithmetic is bit-identical to the CPU oracle
 # -munsafe-fp-atomics : atomicAdd(float*) -> global_atomic_add_f32 (no CAS loop)
-# NO_PACKED_FP32     : no packed-fp32 VALU (v_pk_add/mul/fma_f32): the target feature is switched off for the device pass (the
-#                     host pass says it does not know the feature: filtered below) and the SLP vectoriser, which would only
-#                     build vectors to be taken apart again, too.  hipcc packs adjacent scalar fp32 operations into them,
-#                     and on gfx950 two kernels gave results that changed from run to run until they were gone: the fused
-#                     Adam epilogue of brick.hip beside the weight-gradient kernel of shade.hip (one half of a v_pk_fma_f32 /
-#                     v_pk_mul_f32 op_sel result lost: first moment and parameter of components 1, 5, 9 not updated), and
-#                     round 2's withdrawn prefetch in shade_bwd_x3 (profiles/r3/packed_f32.md).
-#                     tests/test_hazards.py holds every kernel to it.
-NO_PACKED_FP32 = ['-fno-slp-vectorize', '-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops']
 FLAGS = ['-O3', '--offload-arch=gfx950', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off',
-         '-munsafe-fp-atomics', '-fno-gpu-rdc', '-Wall', '-Wno-unused-function'] + NO_PACKED_FP32
+         '-munsafe-fp-atomics', '-fno-gpu-rdc', '-Wall', '-Wno-unused-function']
 
 
 def needs_build():
@@ -45,18 +36,13 @@ def build(force=False, verbose=True, extra_flags=()):
     procs = []
     for f in SOURCES:   # compile the translation units in parallel, then link
         o = os.path.join(CSRC, f.replace('.hip', '.o'))
-        per_file = os.environ.get('DVGO_FLAGS_' + f.replace('.hip', '').upper(), '').split()   # e.g. DVGO_FLAGS_SHADE_X3='-mllvm ...'
-        cmd = [hipcc] + [x for x in FLAGS if x != '-shared'] + list(extra_flags) + per_file + ['-c', os.path.join(CSRC, f), '-o', o]
+        cmd = [hipcc] + [x for x in FLAGS if x != '-shared'] + list(extra_flags) + ['-c', os.path.join(CSRC, f), '-o', o]
         if verbose:
             print(' '.join(cmd), flush=True)
-        procs.append((cmd, subprocess.Popen(cmd, stderr=subprocess.PIPE, text=True)))
+        procs.append((cmd, subprocess.Popen(cmd)))
         objs.append(o)
     for cmd, p in procs:
-        err = p.communicate()[1]
-        err = '\n'.join(ln for ln in err.splitlines() if 'is not a recognized feature for this target' not in ln)   # (host pass, NO_PACKED_FP32)
-        if err.strip():
-            print(err, file=sys.stderr, flush=True)
-        if p.returncode != 0:
+        if p.wait() != 0:
             raise RuntimeError('hipcc failed: ' + ' '.join(cmd))
     cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-fno-gpu-rdc', '-o', SO] + objs
     if verbose:

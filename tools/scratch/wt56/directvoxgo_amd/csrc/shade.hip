@@ -21,27 +21,26 @@
 // per workgroup) and the activations never leave their registers.
 // Layer 3 (3 outputs) is 192 VALU FMAs per lane plus one cross-half add.
 #include "common.h"
-#include "x3.h"
 
 #include <type_traits>
 
+using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 static int g_shade_experiment = 0;   // timing experiments only (tools/): bit 0 = skip G1/G2 stores in shade_bwd
 // kernel variants (dvgo_shade_variant): bit 0 = forward, bit 1 = data gradients, bit 2 = weight gradients on the bf16
 // matrix cores with a 3-way operand split (shade_x3.hip)
-static int g_shade_variant = 67;        // include/dvgo_hip.h: dvgo_shade_variant
+static int g_shade_variant = 3;
 extern "C" int dvgo_shade_wgrad_x3(const float* G1, const float* gz, const uint64_t* masks, const float* W3, const float* H1,
                                    const float* H2, const float* feat, int C, const float* emb, int E, const int64_t* ray_id,
-                                   int64_t M, const int64_t* m_dev, int width, int diffuse, int n_parts, float* part, int form_b,
-                                   void* stream);
+                                   int64_t M, const int64_t* m_dev, int width, int diffuse, int n_parts, float* part, void* stream);
 extern "C" int dvgo_shade_bwd_x3(const float* g_rgb, const float* rgb, const uint64_t* masks, int64_t M, const int64_t* m_dev,
                                  const float* W1, const float* W2, const float* W3, int width, int d_in, int C, int diffuse,
-                                 float* g_feat, float* G1, float* gz, void* scratch, int prebuilt, void* stream);
+                                 float* g_feat, float* G1, float* gz, void* scratch, void* stream);
 
 extern "C" int dvgo_shade_fwd_x3(const float* feat, int C, const float* emb, int E, const int64_t* ray_id, int64_t M, const int64_t* m_dev,
                                  const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
                                  const float* b3, int width, int d_in, int diffuse, float* rgb, float* H1, float* H2,
-                                 uint64_t* masks, void* scratch, void* scratch_bwd, int experiment, void* stream);
+                                 uint64_t* masks, void* scratch, int experiment, void* stream);
 
 // Saved activations / gradients are plain row-major [M, features]: in the accumulator layout a lane owns
 // 4 consecutive features per register quad, i.e. one 16-byte piece of its row.
@@ -627,10 +626,8 @@ shade_wgrad_ring_kernel(const float* __restrict__ G1, const float* __restrict__ 
                         const float* __restrict__ W3, const float* __restrict__ H1, const float* __restrict__ H2,
                         const float* __restrict__ feat, int C, int c_view0, int n_view, const float* __restrict__ emb, int E,
                         const int64_t* __restrict__ ray_id, int64_t M_cap, const int64_t* __restrict__ m_dev,
-                        float* __restrict__ part /* [gridDim][WIDTH*WIDTH + WIDTH*64 + 32*WIDTH + 3*WIDTH] */,
-                        float* __restrict__ total, int total_size /* zeroed here for the reduce kernel's atomics */) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total_size; i += gridDim.x * blockDim.x) total[i] = 0.0f;   // buffer descriptors are device-only types: the host pass needs the launch stub only
+                        float* __restrict__ part /* [gridDim][WIDTH*WIDTH + WIDTH*64 + 32*WIDTH + 3*WIDTH] */) {
+#if defined(__HIP_DEVICE_COMPILE__)   // buffer descriptors are device-only types: the host pass needs the launch stub only
   // (everything the DMA descriptors, scalar offsets and LDS targets are built from must be PROVABLY wave-uniform, or the
   // compiler wraps each DMA in a readfirstlane loop: the row count comes from memory, the wave index from threadIdx)
   int64_t M;
@@ -873,314 +870,16 @@ shade_wgrad_ring_kernel(const float* __restrict__ G1, const float* __restrict__ 
   }
 #endif
 }
-// ----------------------------------------------------------------------------------
-// The same pipeline with the contraction on the bf16 matrix cores (round 3; dvgo_shade_variant bit 6).  Data movement is
-// the ring kernel's, unchanged: 16-row tiles of every operand by LDS-DMA one tile ahead, two workgroups per CU.  The body:
-//   * wave w reads ITS columns of the tile in MFMA fragment order -- lane (column j, half h) holds rows 8h .. 8h+7 -- and
-//     splits each value exactly into three bf16 pieces (x3.h): the A fragments of its own out-feature tile (G2 rebuilt
-//     from gz and the sign bits, G1) stay in registers; the B fragment of ONE in-feature tile of H1 (waves 0 / 1: also one
-//     of the two X tiles) goes to LDS, where all four waves read it: nothing is split twice (the barrier-free form splits
-//     every H1 tile in every wave: 2.2x the VALU work, and VALU work is what bounds these kernels);
-//   * second barrier; 36 MFMAs per wave and tile (4 x 6 for dW2, 2 x 6 for dW1: the trailing X columns are a second
-//     MFMA tile here instead of 64 FMAs), fragments read from LDS two tiles at a time, MFMAs of two accumulators alternating.
-// ----------------------------------------------------------------------------------
-template <int OFF> __device__ __forceinline__ u32x4 lds_u32x4(unsigned a) {
-  u32x4 v; asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF)); return v;
-}
-template <int OFF> __device__ __forceinline__ void lds_store_u32x4(unsigned a, u32x4 v) {
-  asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(a), "v"(v), "n"(OFF) : "memory");
-}
-
-template <int WIDTH>
-struct ShadeWgradRingX3 : ShadeWgradRing<WIDTH> {
-  u32x4 fb[WIDTH / 32 + 2][3][64];     // shared B fragments: [in-feature tile of H1, then the two X tiles][piece][lane]
-};
-
-template <int WIDTH>
-__global__ void __launch_bounds__(2 * WIDTH, 2)
-shade_wgrad_ring_x3_kernel(const float* __restrict__ G1, const float* __restrict__ gz, const unsigned int* __restrict__ masks,
-                           const float* __restrict__ W3, const float* __restrict__ H1, const float* __restrict__ H2,
-                           const float* __restrict__ feat, int C, int c_view0, int n_view, const float* __restrict__ emb, int E,
-                           const int64_t* __restrict__ ray_id, int64_t M_cap, const int64_t* __restrict__ m_dev,
-                           float* __restrict__ part, float* __restrict__ total, int total_size) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total_size; i += gridDim.x * blockDim.x) total[i] = 0.0f;
-  int64_t M;
-  {
-    const int64_t m = m_dev ? (*m_dev < M_cap ? *m_dev : M_cap) : M_cap;
-    M = ((int64_t)__builtin_amdgcn_readfirstlane((int)(m >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)m);
-  }
-  using Ring = ShadeWgradRingX3<WIDTH>;
-  constexpr int T = WIDTH / 32, NW = T, NB = Ring::NB, NR = Ring::NR, TR = Ring::TR;
-  static_assert(T == 4 || T == 2, "widths 128 and 64");
-  constexpr int LPR = WIDTH / 4, RPI = 64 / LPR, IPW = TR / RPI / NW, FPW = 4 / NW, EPW = 8 / NW;
-  static_assert(IPW == 2 && NB == 2 && TR == 16, "double buffer of 16-row tiles: the wait at the top of a tile is vmcnt(0)");
-  __shared__ __attribute__((aligned(16))) Ring L;
-  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, j = lane & 31;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  f32x16 aW2[T], aW1[2];
-  float vW3[3] = {0.0f, 0.0f, 0.0f}, sgz[3] = {0.0f, 0.0f, 0.0f};
-#pragma unroll
-  for (int t = 0; t < T; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) aW2[t][r] = 0.0f;
-#pragma unroll
-  for (int q = 0; q < 2; ++q)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) aW1[q][r] = 0.0f;
-  float sb1 = 0.0f, sb2 = 0.0f;
-  const float w30 = W3[32 * w + j], w31 = W3[WIDTH + 32 * w + j], w32 = W3[2 * WIDTH + 32 * w + j];
-  const int m_idx = 2 * ((j >> 2) & 1) + (w >> 1);
-  const unsigned m_bit = 16 * (w & 1) + (j & 3) + 4 * (j >> 3);
-  const int d_in = n_view + E;
-  const int n_tiles = (int)((M + TR - 1) / TR);
-  auto tile_of = [&](int k) { return (int)blockIdx.x + k * (int)gridDim.x; };
-  const unsigned rows_b = (unsigned)(M * WIDTH * 4);
-  const auto bG1 = __builtin_amdgcn_make_buffer_rsrc((void*)G1, 0, rows_b, 0x00020000);
-  const auto bH1 = __builtin_amdgcn_make_buffer_rsrc((void*)H1, 0, rows_b, 0x00020000);
-  const auto bH2 = __builtin_amdgcn_make_buffer_rsrc((void*)H2, 0, rows_b, 0x00020000);
-  const auto bF = __builtin_amdgcn_make_buffer_rsrc((void*)feat, 0, (unsigned)(M * C * 4), 0x00020000);
-  const auto bE = __builtin_amdgcn_make_buffer_rsrc((void*)emb, 0, DVGO_OOB, 0x00020000);
-  const auto bGz = __builtin_amdgcn_make_buffer_rsrc((void*)gz, 0, (unsigned)(M * 12), 0x00020000);
-  const auto bM = __builtin_amdgcn_make_buffer_rsrc((void*)masks, 0, (unsigned)(M * 32), 0x00020000);
-  const auto bR = __builtin_amdgcn_make_buffer_rsrc((void*)ray_id, 0, (unsigned)(M * 8), 0x00020000);
-  unsigned vo_bulk[IPW], vo_f[FPW], vo_ecol[EPW];
-  int e_row[EPW];
-#pragma unroll
-  for (int i = 0; i < IPW; ++i) vo_bulk[i] = (unsigned)(((IPW * w + i) * RPI + lane / LPR) * WIDTH * 4 + 16 * (lane % LPR));
-#pragma unroll
-  for (int i = 0; i < FPW; ++i) {
-    const int e = 64 * (w + NW * i) + lane, row = e >> 4, col = e & 15;
-    vo_f[i] = col < n_view ? (unsigned)((row * C + c_view0 + col) * 4) : DVGO_OOB;
-  }
-#pragma unroll
-  for (int i = 0; i < EPW; ++i) {
-    const int e = 64 * (w + NW * i) + lane, col = e & 31;
-    e_row[i] = e >> 5;
-    vo_ecol[i] = col < E ? (unsigned)(col * 4) : DVGO_OOB;
-  }
-  const unsigned vo_gz = (lane & 3) < 3 ? (unsigned)(((lane >> 2) * 3 + (lane & 3)) * 4) : DVGO_OOB;
-  const unsigned vo_m2 = (unsigned)(((lane >> 2) * 8 + 4 + (lane & 3)) * 4);
-  const unsigned vo_rid = (unsigned)((lane & (TR - 1)) * 8);
-  auto issue = [&](int t) {           // (the ring kernel's group: tile t, and the ray ids of tile t + 2)
-    const int sl = t & (NB - 1);
-    const unsigned r0 = (unsigned)__builtin_amdgcn_readfirstlane(tile_of(t) * TR);
-#pragma unroll
-    for (int i = 0; i < IPW; ++i) {
-      const int rl = (IPW * w + i) * RPI;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(bG1, (dvgo_lptr_t)&L.g1[sl][rl][0], 16, vo_bulk[i], r0 * (WIDTH * 4), 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(bH1, (dvgo_lptr_t)&L.h1[sl][rl][0], 16, vo_bulk[i], r0 * (WIDTH * 4), 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(bH2, (dvgo_lptr_t)&L.h2[sl][rl][0], 16, vo_bulk[i], r0 * (WIDTH * 4), 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < FPW; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(bF, (dvgo_lptr_t)(&L.xf[sl][0][0] + 64 * (w + NW * i)), 4, vo_f[i], r0 * (unsigned)(C * 4), 0, 0);
-    unsigned rids[EPW];
-#pragma unroll
-    for (int i = 0; i < EPW; ++i) rids[i] = lds_u32<0>(lds_addr(&L.rid[t & (NR - 1)][e_row[i]]));
-    if constexpr (EPW == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rids[0]), "+v"(rids[1]));
-    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rids[0]), "+v"(rids[1]), "+v"(rids[EPW - 2]), "+v"(rids[EPW - 1]));
-#pragma unroll
-    for (int i = 0; i < EPW; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(bE, (dvgo_lptr_t)(&L.xe[sl][0][0] + 64 * (w + NW * i)), 4,
-                                               vo_ecol[i] + rids[i] * (unsigned)(E * 4), 0, 0, 0);
-    const unsigned rn = (unsigned)__builtin_amdgcn_readfirstlane(tile_of(t + 2) * TR);
-    const int rsl = (t + 2) & (NR - 1);
-    auto small = [&](int which) {
-      if (which == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(bGz, (dvgo_lptr_t)&L.gz[sl][0][0], 4, vo_gz, r0 * 12u, 0, 0);
-      else if (which == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(bM, (dvgo_lptr_t)&L.m2[sl][0][0], 4, vo_m2, r0 * 32u, 0, 0);
-      else __builtin_amdgcn_raw_ptr_buffer_load_lds(bR, (dvgo_lptr_t)&L.rid[rsl][0], 4, vo_rid, rn * 8u, 0, 0);
-    };
-    if constexpr (NW == 4) {
-      small(w < 2 ? w : 2);
-    } else {
-      small(w);
-      small(2);
-    }
-  };
-  // this lane's operand addresses in slot 0: its column, rows 8h .. 8h + 7 (the row enters as the immediate offset)
-  const unsigned a_gz = lds_addr(&L.gz[0][8 * h][0]), a_mw = lds_addr(&L.m2[0][8 * h][m_idx]);
-  const unsigned a_g1 = lds_addr(&L.g1[0][8 * h][32 * w + j]), a_h1 = lds_addr(&L.h1[0][8 * h][32 * w + j]);
-  const unsigned a_h2 = lds_addr(&L.h2[0][8 * h][32 * w + j]);
-  // the X tile wave q (= 0, 1) splits: column 32 q + j of X = a feature column (k < n_view), an embedding column, or nothing
-  const int xcol = 32 * (w & 1) + j;
-  const bool x_in_f = xcol < n_view, x_ok = xcol < d_in;
-  const unsigned a_x = x_in_f ? lds_addr(&L.xf[0][8 * h][xcol]) : lds_addr(&L.xe[0][8 * h][x_ok ? xcol - n_view : 0]);
-  const unsigned a_fb = lds_addr(&L.fb[0][0][lane]);
-  constexpr unsigned SLOT_ROWS = TR * WIDTH * 4, FB_TILE = 3 * 64 * 16, FB_PIECE = 64 * 16;
-  if (tid < 64) {
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int64_t row = (int64_t)tile_of(t) * TR + (tid & (TR - 1));
-      L.rid[t][tid] = row < M ? (unsigned int)ray_id[row] : 0u;
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int t = 0; t < NB - 1; ++t) issue(t);
-  for (int k = 0; tile_of(k) < n_tiles; ++k) {
-    const int sl = k & (NB - 1);
-    // behind the barrier every wave's share of tile k has landed and every wave is done with tile k - 1: its slot (group
-    // k + 1 overwrites it) and the shared fragments
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    issue(k + NB - 1);
-    const unsigned b_gz = a_gz + sl * (TR * 16), b_mw = a_mw + sl * (TR * 16), b_g1 = a_g1 + sl * SLOT_ROWS;
-    const unsigned b_h1 = a_h1 + sl * SLOT_ROWS, b_h2 = a_h2 + sl * SLOT_ROWS;
-    const unsigned b_x = a_x + sl * (x_in_f ? (unsigned)(TR * 16 * 4) : (unsigned)(TR * 32 * 4));
-    dvgo_f32x4 gq[8];
-    unsigned mw[8];
-    float g1v[8], h1v[8], h2v[8], xv[8];
-    static_for<0, 8>([&](auto Ec) {
-      constexpr int e = decltype(Ec)::value;
-      h1v[e] = lds_f32<e * WIDTH * 4>(b_h1);
-    });
-    if (w < 2) {
-      if (x_in_f) static_for<0, 8>([&](auto Ec) { constexpr int e = decltype(Ec)::value; xv[e] = lds_f32<e * 16 * 4>(b_x); });
-      else static_for<0, 8>([&](auto Ec) { constexpr int e = decltype(Ec)::value; xv[e] = lds_f32<e * 32 * 4>(b_x); });
-    }
-    static_for<0, 8>([&](auto Ec) {
-      constexpr int e = decltype(Ec)::value;
-      gq[e] = lds_f32x4<16 * e>(b_gz);                 // broadcast
-      mw[e] = lds_u32<16 * e>(b_mw);
-      g1v[e] = lds_f32<e * WIDTH * 4>(b_g1);
-      h2v[e] = lds_f32<e * WIDTH * 4>(b_h2);
-    });
-    // the shared B fragments first: the other waves wait for them
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h1v[0]), "+v"(h1v[1]), "+v"(h1v[2]), "+v"(h1v[3]), "+v"(h1v[4]), "+v"(h1v[5]),
-                 "+v"(h1v[6]), "+v"(h1v[7]), "+v"(gq[0]), "+v"(gq[1]), "+v"(gq[2]), "+v"(gq[3]), "+v"(gq[4]), "+v"(gq[5]), "+v"(gq[6]),
-                 "+v"(gq[7]));
-    asm volatile("" : "+v"(mw[0]), "+v"(mw[1]), "+v"(mw[2]), "+v"(mw[3]), "+v"(mw[4]), "+v"(mw[5]), "+v"(mw[6]), "+v"(mw[7]),
-                 "+v"(g1v[0]), "+v"(g1v[1]), "+v"(g1v[2]), "+v"(g1v[3]), "+v"(g1v[4]), "+v"(g1v[5]), "+v"(g1v[6]), "+v"(g1v[7]));
-    asm volatile("" : "+v"(h2v[0]), "+v"(h2v[1]), "+v"(h2v[2]), "+v"(h2v[3]), "+v"(h2v[4]), "+v"(h2v[5]), "+v"(h2v[6]), "+v"(h2v[7]));
-    {
-      u32x4 p0, p1, p2;
-      x3_split8(h1v, p0, p1, p2);
-      lds_store_u32x4<0>(a_fb + w * FB_TILE, p0);
-      lds_store_u32x4<FB_PIECE>(a_fb + w * FB_TILE, p1);
-      lds_store_u32x4<2 * FB_PIECE>(a_fb + w * FB_TILE, p2);
-      if (w < 2) {
-        asm volatile("" : "+v"(xv[0]), "+v"(xv[1]), "+v"(xv[2]), "+v"(xv[3]), "+v"(xv[4]), "+v"(xv[5]), "+v"(xv[6]), "+v"(xv[7]));
-#pragma unroll
-        for (int e = 0; e < 8; ++e) xv[e] = x_ok ? xv[e] : 0.0f;
-        x3_split8(xv, p0, p1, p2);
-        lds_store_u32x4<0>(a_fb + (T + w) * FB_TILE, p0);
-        lds_store_u32x4<FB_PIECE>(a_fb + (T + w) * FB_TILE, p1);
-        lds_store_u32x4<2 * FB_PIECE>(a_fb + (T + w) * FB_TILE, p2);
-      }
-    }
-    // this wave's A fragments: G2 rebuilt from gz and the layer-2 sign bit (zeros on rows past M), G1 as read; fp32 tails
-    u32x4 a2f[3], a1f[3];
-    {
-      float a2[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float g2v = fmaf(w32, gq[e].z, fmaf(w31, gq[e].y, w30 * gq[e].x));
-        a2[e] = __uint_as_float(__float_as_uint(g2v) & (unsigned)__builtin_amdgcn_sbfe((int)mw[e], m_bit, 1u));
-        sb2 += a2[e]; sb1 += g1v[e];
-        vW3[0] = fmaf(gq[e].x, h2v[e], vW3[0]); vW3[1] = fmaf(gq[e].y, h2v[e], vW3[1]); vW3[2] = fmaf(gq[e].z, h2v[e], vW3[2]);
-      }
-      if (w == 0) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { sgz[0] += gq[e].x; sgz[1] += gq[e].y; sgz[2] += gq[e].z; }
-      }
-      x3_split8(a2, a2f[0], a2f[1], a2f[2]);
-      x3_split8(g1v, a1f[0], a1f[1], a1f[2]);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");        // the shared fragments are complete
-    // 36 MFMAs: fragments two tiles at a time, the MFMAs of the two accumulators alternating (no dependent pair back to back)
-    u32x4 fr[2][2][3];
-    auto read_pair = [&](auto Pc, u32x4 (&f)[2][3]) {
-      constexpr int p = decltype(Pc)::value;                      // tiles 2p, 2p + 1 of fb
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        f[0][q] = lds_u32x4<(2 * p) * FB_TILE>(a_fb + q * FB_PIECE);
-        f[1][q] = lds_u32x4<(2 * p + 1) * FB_TILE>(a_fb + q * FB_PIECE);
-      }
-    };
-    auto wait_pair = [&](u32x4 (&f)[2][3]) {
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0][0]), "+v"(f[0][1]), "+v"(f[0][2]), "+v"(f[1][0]), "+v"(f[1][1]), "+v"(f[1][2]));
-    };
-    auto mfma_pair = [&](f32x16& accA, f32x16& accB, const u32x4 (&a)[3], const u32x4 (&f)[2][3]) {
-#define X3D_MF(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), ACC, 0, 0, 0)
-      X3D_MF(accA, a[2], f[0][0]); X3D_MF(accB, a[2], f[1][0]);       // smallest terms first (x3_mfma6's order per accumulator)
-      X3D_MF(accA, a[1], f[0][1]); X3D_MF(accB, a[1], f[1][1]);
-      X3D_MF(accA, a[0], f[0][2]); X3D_MF(accB, a[0], f[1][2]);
-      X3D_MF(accA, a[1], f[0][0]); X3D_MF(accB, a[1], f[1][0]);
-      X3D_MF(accA, a[0], f[0][1]); X3D_MF(accB, a[0], f[1][1]);
-      X3D_MF(accA, a[0], f[0][0]); X3D_MF(accB, a[0], f[1][0]);
-#undef X3D_MF
-    };
-    constexpr int NP = T / 2 + 1;                                  // pairs of tiles: T / 2 of H1, then the X pair
-    read_pair(std::integral_constant<int, 0>{}, fr[0]);
-    static_for<0, NP>([&](auto Pc) {
-      constexpr int p = decltype(Pc)::value;
-      wait_pair(fr[p & 1]);
-      if constexpr (p + 1 < NP) read_pair(std::integral_constant<int, p + 1>{}, fr[(p + 1) & 1]);
-      if constexpr (p < T / 2) mfma_pair(aW2[2 * p], aW2[2 * p + 1], a2f, fr[p & 1]);
-      else mfma_pair(aW1[0], aW1[1], a1f, fr[p & 1]);
-      __builtin_amdgcn_sched_barrier(0);
-    });
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the run-ahead groups: nothing may land after the workgroup is gone
-  float* p = part + (int64_t)blockIdx.x * (WIDTH * WIDTH + WIDTH * 64 + 32 * WIDTH + 3 * WIDTH);
-  float* pW2 = p;
-  float* pW1 = pW2 + WIDTH * WIDTH;
-  float* pW3 = pW1 + WIDTH * 64;
-  float* pb = pW3 + 32 * WIDTH;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
-#pragma unroll
-    for (int t = 0; t < T; ++t) pW2[(32 * w + i) * WIDTH + 32 * t + j] = aW2[t][r];
-    pW1[(32 * w + i) * 64 + j] = aW1[0][r];
-    pW1[(32 * w + i) * 64 + 32 + j] = aW1[1][r];
-  }
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    const float v = vW3[c] + __shfl_xor(vW3[c], 32);
-    if (h == 0) pW3[c * WIDTH + 32 * w + j] = v;
-    sgz[c] += __shfl_xor(sgz[c], 32);
-  }
-  sb1 += __shfl_xor(sb1, 32); sb2 += __shfl_xor(sb2, 32);
-  if (h == 0) {
-    pb[32 * w + j] = sb1;
-    pb[WIDTH + 32 * w + j] = sb2;
-    if (j < 8) pb[2 * WIDTH + 8 * w + j] = (w == 0 && j < 3) ? sgz[j] : 0.0f;
-    if (T == 2 && j >= 16) pb[2 * WIDTH + 16 * w + j] = 0.0f;
-  }
-#endif
-}
 #undef DVGO_OOB
 
 // sum of the per-workgroup partials: [n_parts][n] -> [n].  blockIdx.y takes a slice of the parts so that a few
 // thousand wavefronts stream the 60 MB (one column block alone would leave the chip idle and latency-bound:
 // 124 us -> ~20 us); slices meet in `out` (zeroed by the caller) with one float atomic per element.
 #define SHADE_REDUCE_SLICES 16
-// The sums leave in the COMPACT record the caller hands to the optimizer as views, no repacking launches:
-//   { dW2 [W][W], dW1 [W][d_in], dW3 [3][W], db1 [W], db2 [W], db3 [3] }   (the padded columns / rows of a part are dropped,
-//   the two halves of db3 meet here)
 __global__ void __launch_bounds__(256)
-shade_wgrad_reduce_kernel(const float* __restrict__ part, int n_parts, int n, int W, int d_in, float* __restrict__ out) {
+shade_wgrad_reduce_kernel(const float* __restrict__ part, int n_parts, int n, float* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  int o;                                    // index in the compact record, -1: padding
-  const int nW2 = W * W, nW1 = W * 64, nW3 = 32 * W;
-  if (i < nW2) o = i;
-  else if (i < nW2 + nW1) {
-    const int r = (i - nW2) >> 6, c = (i - nW2) & 63;
-    o = c < d_in ? nW2 + r * d_in + c : -1;
-  } else if (i < nW2 + nW1 + nW3) {
-    const int e = i - nW2 - nW1;
-    o = e < 3 * W ? nW2 + W * d_in + e : -1;
-  } else {
-    const int e = i - nW2 - nW1 - nW3, base = nW2 + W * d_in + 3 * W;
-    if (e < 2 * W) o = base + e;
-    else {
-      const int c = e - 2 * W;
-      o = c < 3 ? base + 2 * W + c : (c >= 8 && c < 11) ? base + 2 * W + c - 8 : -1;
-    }
-  }
-  if (o < 0) return;
   const int per = (n_parts + SHADE_REDUCE_SLICES - 1) / SHADE_REDUCE_SLICES;
   const int p0 = blockIdx.y * per, p1 = min(n_parts, p0 + per);
   float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
@@ -1192,7 +891,7 @@ shade_wgrad_reduce_kernel(const float* __restrict__ part, int n_parts, int n, in
     a3 += part[(int64_t)(p + 3) * n + i];
   }
   for (; p < p1; ++p) a0 += part[(int64_t)p * n + i];
-  if (p1 > p0) atomicAdd(out + o, (a0 + a1) + (a2 + a3));
+  if (p1 > p0) atomicAdd(out + i, (a0 + a1) + (a2 + a3));
 }
 
 extern "C" {
@@ -1200,7 +899,7 @@ extern "C" {
 int dvgo_shade_fwd(const float* feat, int C, const float* emb, int E, const int64_t* ray_id, int64_t M, const int64_t* m_dev,
                    const float* W1, const float* b1, const float* W2, const float* b2, const float* W3,
                    const float* b3, int width, int d_in, int diffuse, float* rgb, float* H1, float* H2,
-                   uint64_t* masks, void* scratch, void* scratch_bwd, void* stream) {
+                   uint64_t* masks, void* scratch, void* stream) {
   if (M < 0 || C <= 0 || E < 0) return DVGO_EINVAL;
   if (M == 0) return 0;
   if (!feat || !emb || !ray_id || !W1 || !b1 || !W2 || !b2 || !W3 || !b3 || !rgb) return DVGO_EINVAL;
@@ -1211,7 +910,7 @@ int dvgo_shade_fwd(const float* feat, int C, const float* emb, int E, const int6
   if ((width != 128 && width != 64) || d_in > 40) return DVGO_ERANGE;   // outside the instantiated set: caller falls back
   if ((g_shade_variant & 1) && scratch != nullptr)
     return dvgo_shade_fwd_x3(feat, C, emb, E, ray_id, M, m_dev, W1, b1, W2, b2, W3, b3, width, d_in, diffuse, rgb, H1, H2, masks,
-                             scratch, (g_shade_variant & 2) ? scratch_bwd : nullptr, g_shade_experiment, stream);
+                             scratch, g_shade_experiment, stream);
   hipStream_t s = (hipStream_t)stream;
   const int64_t n_tiles = (M + 31) / 32;
   const int64_t cap = width == 128 ? 256 : 512;          // width 128: one workgroup per CU (LDS); width 64: two
@@ -1239,7 +938,7 @@ int dvgo_shade_variant(int flags) { const int old = g_shade_variant; if (flags >
 
 int dvgo_shade_bwd(const float* g_rgb, const float* rgb, const uint64_t* masks, int64_t M, const int64_t* m_dev,
                    const float* W1, const float* W2, const float* W3, int width, int d_in, int C, int diffuse,
-                   float* g_feat, float* G1, float* gz, void* scratch, int prebuilt, void* stream) {
+                   float* g_feat, float* G1, float* gz, void* scratch, void* stream) {
   if (M < 0 || C <= 0) return DVGO_EINVAL;
   if (M == 0) return 0;
   if (!g_rgb || !rgb || !masks || !W1 || !W2 || !W3 || !g_feat || !G1 || !gz) return DVGO_EINVAL;
@@ -1247,7 +946,7 @@ int dvgo_shade_bwd(const float* g_rgb, const float* rgb, const uint64_t* masks, 
   const int n_view = C - c_view0;
   if ((width != 128 && width != 64) || n_view < 0 || n_view > 32 || d_in < n_view) return DVGO_ERANGE;
   if ((g_shade_variant & 2) && scratch != nullptr)
-    return dvgo_shade_bwd_x3(g_rgb, rgb, masks, M, m_dev, W1, W2, W3, width, d_in, C, diffuse, g_feat, G1, gz, scratch, prebuilt, stream);
+    return dvgo_shade_bwd_x3(g_rgb, rgb, masks, M, m_dev, W1, W2, W3, width, d_in, C, diffuse, g_feat, G1, gz, scratch, stream);
   hipStream_t s = (hipStream_t)stream;
   const int64_t n_tiles = (M + 31) / 32;
   const int64_t cap = width == 128 ? 256 : 512;
@@ -1270,31 +969,19 @@ int dvgo_shade_wgrad(const float* G1, const float* gz, const uint64_t* masks, co
   const int c_view0 = diffuse ? 3 : 0;
   const int n_view = C - c_view0;
   if ((width != 128 && width != 64) || n_view < 0 || n_view + E > 40) return DVGO_ERANGE;
-  bool ring = false;                        // (the pipelined kernel zeroes `total` itself: one launch less)
-  if (g_shade_variant & (4 | 32)) {
-    // bit 5: two barrier-free kernels; bit 4: 4-wave workgroups, two per CU (68 KB of LDS each)
-    const int form_b = (g_shade_variant & 32) ? (2 | (((g_shade_experiment >> 12) & 7) << 8)) : (g_shade_variant & 16) ? 1 : 0;
-    if (!form_b && n_parts > 256) n_parts = 256;           // else: one 8-wave workgroup per CU (141 KB of LDS)
-    const int rc = dvgo_shade_wgrad_x3(G1, gz, masks, W3, H1, H2, feat, C, emb, E, ray_id, M, m_dev, width, diffuse, n_parts, part,
-                                       form_b, stream);
+  if (g_shade_variant & 4) {
+    if (n_parts > 256) n_parts = 256;       // one 8-wave workgroup per CU (141 KB of LDS)
+    const int rc = dvgo_shade_wgrad_x3(G1, gz, masks, W3, H1, H2, feat, C, emb, E, ray_id, M, m_dev, width, diffuse, n_parts, part, stream);
     if (rc != 0) return rc;
   } else if (!(g_shade_variant & 8) && n_view <= 16 && E <= 32 && (n_view + E <= 32 || (n_view % 4 == 0 && n_view >= 8)) &&
              M * width * 4 < ((int64_t)1 << 31) && M * C * 4 < ((int64_t)1 << 31)) {
-    if (n_parts > 512) n_parts = 512;       // two workgroups per CU (55 KB of LDS each; 74 KB with the shared fragments)
-    ring = true;
-    const int tsz = width * width + width * (n_view + E) + 5 * width + 3;
-    if ((g_shade_variant & 64) && width == 128)
-      shade_wgrad_ring_x3_kernel<128><<<n_parts, 256, 0, (hipStream_t)stream>>>(
-          G1, gz, (const unsigned int*)masks, W3, H1, H2, feat, C, c_view0, n_view, emb, E, ray_id, M, m_dev, part, total, tsz);
-    else if (g_shade_variant & 64)
-      shade_wgrad_ring_x3_kernel<64><<<n_parts, 128, 0, (hipStream_t)stream>>>(
-          G1, gz, (const unsigned int*)masks, W3, H1, H2, feat, C, c_view0, n_view, emb, E, ray_id, M, m_dev, part, total, tsz);
-    else if (width == 128)
+    if (n_parts > 512) n_parts = 512;       // two workgroups per CU (55 KB of LDS each)
+    if (width == 128)
       shade_wgrad_ring_kernel<128><<<n_parts, 256, 0, (hipStream_t)stream>>>(
-          G1, gz, (const unsigned int*)masks, W3, H1, H2, feat, C, c_view0, n_view, emb, E, ray_id, M, m_dev, part, total, tsz);
+          G1, gz, (const unsigned int*)masks, W3, H1, H2, feat, C, c_view0, n_view, emb, E, ray_id, M, m_dev, part);
     else
       shade_wgrad_ring_kernel<64><<<n_parts, 128, 0, (hipStream_t)stream>>>(
-          G1, gz, (const unsigned int*)masks, W3, H1, H2, feat, C, c_view0, n_view, emb, E, ray_id, M, m_dev, part, total, tsz);
+          G1, gz, (const unsigned int*)masks, W3, H1, H2, feat, C, c_view0, n_view, emb, E, ray_id, M, m_dev, part);
   } else if (width == 128)
     shade_wgrad_kernel<128><<<n_parts, 256, 0, (hipStream_t)stream>>>(
         G1, gz, (const unsigned int*)masks, W3, H1, H2, feat, C, c_view0, n_view, emb, E, ray_id, M, m_dev, part);
@@ -1303,11 +990,9 @@ int dvgo_shade_wgrad(const float* G1, const float* gz, const uint64_t* masks, co
         G1, gz, (const unsigned int*)masks, W3, H1, H2, feat, C, c_view0, n_view, emb, E, ray_id, M, m_dev, part);
   DVGO_LAUNCH_CHECK();
   const int psize = width * width + width * 64 + 32 * width + 3 * width;
-  const int d_in = n_view + E;
-  const int tsize = width * width + width * d_in + 3 * width + 2 * width + 3;
-  if (!ring && hipMemsetAsync(total, 0, (size_t)tsize * sizeof(float), (hipStream_t)stream) != hipSuccess) return DVGO_EINVAL;
+  if (hipMemsetAsync(total, 0, (size_t)psize * sizeof(float), (hipStream_t)stream) != hipSuccess) return DVGO_EINVAL;
   shade_wgrad_reduce_kernel<<<dim3((psize + 255) / 256, SHADE_REDUCE_SLICES), 256, 0, (hipStream_t)stream>>>(part, n_parts, psize,
-                                                                                                       width, d_in, total);
+                                                                                                       total);
   DVGO_LAUNCH_CHECK();
   return 0;
 }

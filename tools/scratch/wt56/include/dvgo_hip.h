@@ -45,9 +45,6 @@ int dvgo_abi_version(void);
  * measured variants).  key: one of DVGO_TUNE_*; returns DVGO_EINVAL for an unknown key. */
 #define DVGO_TUNE_FEAT_BWD    0   /* 0 = one atomic per (sample,corner,channel); 1 = LDS de-duplicated rows */
 #define DVGO_TUNE_DENSITY_BWD 1   /* 0 = direct atomics; 1 = LDS de-duplicated */
-#define DVGO_TUNE_DENSITY_FWD 2   /* march_density: 1 = corner loads in flight together as z-pairs + occupancy byte a chunk ahead; 0 = round 2's body */
-#define DVGO_TUNE_GATHER      3   /* march_gather: 1 = corner rows requested four at a time; 0 = one corner per round trip */
-#define DVGO_TUNE_EXPERIMENT  4   /* march_density timing experiments (bit mask, results wrong when non-zero; tools/fwd_ab.py) */
 #define DVGO_TUNE_COUNT       8
 int dvgo_set_tuning(int key, int value);
 
@@ -195,8 +192,8 @@ int dvgo_segment_sum(const float* src, const int64_t* index, int64_t M, int C,
  * --------------------------------------------------------------------------------- */
 typedef struct { int32_t step; float exp_d; float alpha; float T; } dvgo_rec2_t;     /* 16 B */
 
-int dvgo_march_density(float* rays_start, float* rays_dir,
-                       int64_t* n_steps, const int64_t* n_steps_cumsum, int64_t rec_stride,
+int dvgo_march_density(const float* rays_start, const float* rays_dir,
+                       const int64_t* n_steps, const int64_t* n_steps_cumsum, int64_t rec_stride,
                        int64_t n_rays,
                        const float* xyz_min, const float* xyz_max, float stepdist,
                        const uint8_t* mask, int mX, int mY, int mZ,
@@ -208,17 +205,6 @@ int dvgo_march_density(float* rays_start, float* rays_dir,
                        int32_t* brick_cnt /* NULL, or [dvgo_n_bricks(X,Y,Z)] zero-initialised counters: the samples
                                              that entered compositing are counted per brick for the backward's
                                              owner-computes scatter (see "Brick scatter" below) */,
-                       const float* rays_o, const float* rays_d, float near, float far
-                                          /* rays_o != NULL (fixed-stride records, stepdist > 0): K1-K3 of
-                                             dvgo_sample_pts_prepare are computed by this launch and rays_start / rays_dir /
-                                             n_steps are OUTPUTS; NULL: they are inputs */,
-                       int32_t* tail_ticket /* NULL, or one zero-initialised int32 (left at zero): the LAST workgroup to finish
-                                               also does the work of dvgo_march_scans -- off3 [n_rays + 1] = exclusive scan of
-                                               n3 and, when brick_cnt and brick_off are given, the brick tables -- so that no
-                                               scan launch is needed between this call and dvgo_march_gather.  One call at a
-                                               time per ticket word. */,
-                       int64_t* off3, int n_bricks, int32_t* brick_off, int32_t* brick_cursor, int32_t* extra_off,
-                       int32_t* active, int32_t* extra_brick, int n_extra_max, int slice_len,
                        void* stream);
 
 /* dvgo_march_hit: hit[r] = 1 iff ray r has an in-box sample whose nearest occupancy voxel is set -- the fused
@@ -255,12 +241,11 @@ int dvgo_march_composite(const float* weights, const float* rgb /* [M3,3] */,
 /* Backward of the composite w.r.t. weights and rgb (either output may be NULL):
  *   grad_weights[i] = sum_c g[r,c]*rgb[i,c] ; grad_rgb[i,c] = g[r,c]*weights[i], r = ray_id[i].
  *   grad_last (NULL or [n_rays]) = bg * sum_c g[r,c], the gradient w.r.t. alphainv_last (lib/dvgo.py:559),
- *   written by the same launch.  accumulate != 0: grad_rgb and grad_last already hold the gradient of the same two
- *   tensors through another consumer (the loss's rgbper and entropy terms, run.py:381-385) and are added to. */
+ *   written by the same launch. */
 int dvgo_march_composite_bwd(const float* grad_rgb_marched /* [N,3] */, const float* weights,
                              const float* rgb, const int64_t* ray_id, int64_t M3, const int64_t* m_dev, int64_t n_rays,
                              float bg, float* grad_weights /* [M3] */, float* grad_rgb /* [M3,3] */,
-                             float* grad_last, int accumulate, void* stream);
+                             float* grad_last, void* stream);
 
 /* dvgo_march_feat_bwd: scatter grad_feat [M3,C] into grad_k0 (float atomics, de-duplicated per wavefront in LDS;
  *   element strides sC,sX,sY,sZ of the destination).
@@ -327,9 +312,7 @@ int dvgo_brick_slice(void);     /* default slice_len: entries per work item of d
  *   - brick_cnt is CLEARED: it becomes the arrival counter array of the slices. */
 int dvgo_brick_scan(int32_t* brick_cnt, int n_bricks, int32_t* brick_off, int32_t* brick_cursor, int32_t* extra_off,
                     int32_t* active, int32_t* extra_brick /* [n_extra_max] */, int n_extra_max, int slice_len, void* stream);
-/* the ray scan (n3 [n_rays] -> off3 [n_rays + 1], int64) and dvgo_brick_scan in one launch; brick_cnt == NULL: rays only.
- * With bricks, off3 must have n_rays + 2 entries: off3[n_rays + 1] = brick_off[n_bricks], the total list length, so that the
- * caller's one host read (sample total, list total) is 16 contiguous bytes. */
+/* the ray scan (n3 [n_rays] -> off3 [n_rays + 1], int64) and dvgo_brick_scan in one launch; brick_cnt == NULL: rays only */
 int dvgo_march_scans(const int32_t* n3, int64_t n_rays, int64_t* off3, int32_t* brick_cnt, int n_bricks,
                      int32_t* brick_off, int32_t* brick_cursor, int32_t* extra_off, int32_t* active, int32_t* extra_brick,
                      int n_extra_max, int slice_len, void* stream);
@@ -346,14 +329,6 @@ int dvgo_brick_accumulate(const int32_t* brick_off, const int32_t* extra_off, co
                           int masked_density, float beta1, float beta2, float eps,
                           const float* step_sizes_dev /* NULL, or device {step_size_k0, step_size_density}: read instead of
                                                          the two float arguments (a captured step replays with new values) */,
-                          float* tiles, int tiles_mode
-                                      /* data parallel (ray-sharded ranks, replicated grids): the gradient travels as whole brick
-                                         tiles of 512 x round_up(C + 1, 4) floats, one per brick of `active` = the bricks ANY rank
-                                         touched (active[n_bricks] = their number; from dvgo_brick_scan over the all-reduced
-                                         counts).  tiles_mode 2: accumulate this rank's lists and write tiles[i] for every
-                                         brick active[i] (zeros where this rank has no entry); the caller all-reduces `tiles`;
-                                         tiles_mode 3: read tiles[i] and apply the (masked) Adam update of brick active[i] from
-                                         it (lists / recs / rays unused).  0: neither. */,
                           void* stream);
 
 /* Combined gradient rows G [n_vox][row_stride] (built by the two calls above) -> the channels-last feature
@@ -375,13 +350,6 @@ int dvgo_view_weight_accumulate(const float* rays_o, const float* rays_d, int64_
                                 const float* xyz_max, float near, float far, float step, int n_samples, int X, int Y,
                                 int Z, float* acc, void* stream);
 int dvgo_view_count_commit(float* acc, float* count, int64_t n_vox, void* stream);
-/* dvgo_rays_of_view: rays of the pixels [p0, p0 + n) (row-major) of one view -- lib/ray_utils.py:9-85: get_rays (pixel
- *   coordinates, `center` = mode 'center' else 'lefttop', flips, inverse_y), viewdirs = rays_d / |rays_d| (before the NDC
- *   warp, as get_rays_of_a_view), ndc != 0: ndc_rays(H, W, ndc_focal, ndc_near, ...).  K4 = {fx, fy, cx, cy} and c2w (3 x 4,
- *   row-major) are HOST pointers; outputs [n, 3] device arrays (viewdirs may be NULL). */
-int dvgo_rays_of_view(int H, int W, const float* K4, const float* c2w, int inverse_y, int flip_x, int flip_y, int center,
-                      int ndc, float ndc_focal, float ndc_near, int64_t p0, int64_t n,
-                      float* rays_o, float* rays_d, float* viewdirs, void* stream);
 int dvgo_maskout_near_cam(float* density, const float* grid_x, const float* grid_y, const float* grid_z, int X, int Y, int Z,
                           const float* cam_o, int n_cam, float near, float value, void* stream);
 
@@ -401,23 +369,14 @@ int dvgo_shade_fwd(const float* feat, int C, const float* emb, int E, const int6
                    const float* W1, const float* b1, const float* W2, const float* b2,
                    const float* W3, const float* b3, int width, int d_in, int diffuse,
                    float* rgb, float* H1, float* H2, uint64_t* masks,
-                   void* scratch /* NULL, or dvgo_shade_scratch_bytes(width) bytes of device memory */,
-                   void* scratch_bwd /* NULL, or a second block of that size: a training step has the weight image of the
-                                        data-gradient kernel built by the same prep launch (dvgo_shade_bwd: prebuilt = 1) */,
-                   void* stream);
+                   void* scratch /* NULL, or dvgo_shade_scratch_bytes(width) bytes of device memory */, void* stream);
 
 /* Kernel variants of the colour head (process-global, for A/B runs; returns the previous value, negative = query):
  *   bit 0  forward, bit 1 data gradients on the bf16 matrix cores: every fp32 operand split EXACTLY into three bf16
  *          pieces, six partial products per k-step accumulated in fp32 (csrc/shade_x3.hip) -- fp32-grade results at 2.7x
- *          fewer matrix-pipe cycles than v_mfma_f32_32x32x2_f32.  The f32-MFMA kernels run when the bit is
+ *          fewer matrix-pipe cycles than v_mfma_f32_32x32x2_f32.  Default 3; the f32-MFMA kernels run when the bit is
  *          clear or `scratch` is NULL (the bf16 variants keep the pre-split weight image there, built by a small kernel
- *          at every call).
- *   weight gradients (dvgo_shade_wgrad), first match wins:
- *     bit 5 (32)  two barrier-free kernels on the split operands, every operand straight from global memory (shade_x3.hip c1/c2)
- *     bit 2 (4)   split operands staged through LDS, one 8-wave workgroup per CU; + bit 4 (16): 4-wave workgroups, two per CU
- *     bit 6 (64)  the pipelined LDS-DMA ring with the contraction on the split operands, B fragments shared through LDS
- *     none        the pipelined LDS-DMA ring with v_mfma_f32_32x32x2_f32 (bit 3 (8): the round-1 kernel instead)
- *   Default 67 = 1 | 2 | 64 (measured, roofline case: weight gradients 0.93 -> 0.72 ms against the f32 ring). */
+ *          at every call). */
 int64_t dvgo_shade_scratch_bytes(int width);
 int dvgo_shade_variant(int flags);
 
@@ -428,9 +387,7 @@ int dvgo_shade_variant(int flags);
  * channels [0,3) = gz when diffuse, channels [c0, C) = (W1^T G1)[:C-c0]. */
 int dvgo_shade_bwd(const float* g_rgb, const float* rgb, const uint64_t* masks, int64_t M, const int64_t* m_dev,
                    const float* W1, const float* W2, const float* W3, int width, int d_in, int C, int diffuse,
-                   float* g_feat, float* G1, float* gz, void* scratch,
-                   int prebuilt /* scratch already holds this kernel's weight image (dvgo_shade_fwd: scratch_bwd) */,
-                   void* stream);
+                   float* g_feat, float* G1, float* gz, void* scratch, void* stream);
 
 /* Weight-gradient part (G1, gz from dvgo_shade_bwd; masks, H1, H2 from dvgo_shade_fwd; W3 as given to both):
  * dW2 = G2^T H1, dW1 = G1^T X (X = the layer-1 input, re-assembled from feat / emb /
@@ -438,8 +395,7 @@ int dvgo_shade_bwd(const float* g_rgb, const float* rgb, const uint64_t* masks, 
  * with both operands read row-major straight from memory.  Every one of the n_parts workgroups writes its
  * partial sums to part[p] = { dW2 [width][width], dW1 [width][64], dW3 [32][width] (rows 0..2 valid),
  * db1 [width], db2 [width], db3 [width] (db3[c] = entry c + entry 8+c, c < 3) } floats (scratch), and a second launch sums them over p
- * into `total`, the compact record { dW2 [width][width], dW1 [width][d_in], dW3 [3][width], db1 [width], db2 [width], db3 [3] }
- * (d_in = (C - 3 * diffuse) + E; width^2 + width * d_in + 5 * width + 3 floats): views of it are the gradients. */
+ * into `total` (same record layout, once). */
 int dvgo_shade_wgrad(const float* G1, const float* gz, const uint64_t* masks, const float* W3,
                      const float* H1, const float* H2, const float* feat, int C, const float* emb, int E, const int64_t* ray_id, int64_t M,
                      const int64_t* m_dev, int width, int diffuse, int n_parts, float* part, float* total, void* stream);
@@ -494,9 +450,6 @@ int dvgo_loss_fwd_bwd(const float* rgb_marched, const float* alphainv_last, cons
                       const float* raw_rgb, const float* weights, const int64_t* ray_id, int64_t M, const int64_t* m_dev,
                       int64_t n_rays_global, float w_main, float w_ent, float w_per,
                       float* g_marched, float* g_last, float* g_raw_rgb, float* loss_out, void* stream);
-/* dvgo_copy_multi: dst[k][0 .. n_dwords[k]) = src[k][...] for up to 8 (dst, src) pairs of 4-byte elements in ONE launch
- * (harness plumbing: the batch of a captured training step is copied into the graph's input tensors). */
-int dvgo_copy_multi(void* const* dst, const void* const* src, const int64_t* n_dwords, int n_tensors, void* stream);
 int dvgo_viewdir_embed(const float* viewdirs, const float* freq, int n_freq, int64_t N, float* emb, void* stream);
 int dvgo_adam_upd_multi(float* const* params, const float* const* grads, float* const* exp_avg,
                         float* const* exp_avg_sq, const int64_t* numel, int n_tensors, float step_size,

@@ -16,8 +16,15 @@ ap.add_argument('--M', type=int, default=2097152)
 ap.add_argument('--rounds', type=int, default=8)
 ap.add_argument('--variants', default='3,7')
 ap.add_argument('--width', type=int, default=128)
+ap.add_argument('--experiment', type=int, default=0, help='dvgo_shade_experiment flags (switch-off experiments; results are wrong)')
+ap.add_argument('--parts', type=int, default=0, help='override shade.N_PARTS (workgroups of the weight-gradient kernels)')
 args = ap.parse_args()
+if args.parts:
+    import directvoxgo_amd.shade as _sh
+    _sh.N_PARTS = args.parts
 torch.manual_seed(0)
+if args.experiment:
+    L.lib().dvgo_shade_experiment(args.experiment)
 M, N = args.M, 8192
 net = make_rgbnet(39, args.width, 3).cuda()
 feat = torch.randn(M, 12, device='cuda', requires_grad=True)
@@ -40,7 +47,7 @@ for rep in range(2):
             shade(net, feat, emb, ray_id, False).backward(go)
             for n, (c, ms) in L.profile_stop().items():
                 res.setdefault((v, n), []).append(ms / max(c, 1) * 1e3)
-L.lib().dvgo_shade_variant(3)
+L.lib().dvgo_shade_variant(67)
 for (v, n), xs in sorted(res.items()):
     print(f'variant {v}  {n:18s} avg {sum(xs) / len(xs):8.1f} us   min {min(xs):8.1f} us')
 vs = sorted(grads)
