@@ -337,17 +337,32 @@ shade_bwd_x3_kernel(const float* __restrict__ g_rgb, const float* __restrict__ r
   const int64_t n_tiles = (M + 31) / 32;
   const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int64_t nw = (int64_t)gridDim.x * (blockDim.x >> 6);
+  // A wave walks its tiles alone, so the loads at the top of a tile are exposed once per tile: the per-row inputs of tile
+  // i + 1 are requested at the top of tile i.  (Round 2 withdrew exactly this: results then differed from run to run -- the
+  // packed-fp32 instructions of that build, profiles/r3/packed_f32.md; the library is built without them now and
+  // test_shade_is_bitwise_repeatable holds this kernel to repeating bit for bit.)
+  const int64_t last = M > 0 ? M - 1 : 0;
+  float o_n[3], g_n[3];
+  unsigned long long m1_n = 0ull, m2_n = 0ull;
+  auto load_rows = [&](int64_t tile) {
+    const int64_t r = tile * 32 + (lane & 31);
+    const int64_t rc = r < M ? r : last;         // (past the last tile: a clamped row, never used)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { o_n[c] = rgb[rc * 3 + c]; g_n[c] = g_rgb[rc * 3 + c]; }
+    m1_n = masks[(rc * 2 + 0) * 2 + h];
+    m2_n = masks[(rc * 2 + 1) * 2 + h];
+  };
+  if (gw < n_tiles) load_rows(gw);
   for (int64_t tile = gw; tile < n_tiles; tile += nw) {
     const int64_t row = tile * 32 + (lane & 31);
     const bool valid = row < M;
-    const int64_t rowc = valid ? row : (M - 1);
     const int rows_valid = (int)(M - tile * 32 < 32 ? M - tile * 32 : 32);
     float gz[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const float o = rgb[rowc * 3 + c];
-      gz[c] = valid ? g_rgb[rowc * 3 + c] * o * (1.0f - o) : 0.0f;
-    }
+    for (int c = 0; c < 3; ++c) gz[c] = valid ? g_n[c] * o_n[c] * (1.0f - o_n[c]) : 0.0f;
+    // ReLU sign bits of this lane's 64 features per layer (bit 16*t + r <-> feature f(t,r,h))
+    const unsigned long long m1 = m1_n, m2 = m2_n;
+    load_rows(tile + nw);
     if (valid && h == 0) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
@@ -355,9 +370,6 @@ shade_bwd_x3_kernel(const float* __restrict__ g_rgb, const float* __restrict__ r
         if (DIFFUSE) g_feat[row * C + c] = gz[c];
       }
     }
-    // ReLU sign bits of this lane's 64 features per layer (bit 16*t + r <-> feature f(t,r,h))
-    const unsigned long long m1 = masks[(rowc * 2 + 0) * 2 + h];
-    const unsigned long long m2 = masks[(rowc * 2 + 1) * 2 + h];
     // G2 in accumulator layout, split into the B fragments of the W2^T product as it is formed
     u32x4 g3[2 * T][3];
 #pragma unroll
