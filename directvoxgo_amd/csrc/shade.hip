@@ -1273,7 +1273,7 @@ int dvgo_shade_wgrad(const float* G1, const float* gz, const uint64_t* masks, co
   bool ring = false;                        // (the pipelined kernel zeroes `total` itself: one launch less)
   if (g_shade_variant & (4 | 32)) {
     // bit 5: two barrier-free kernels; bit 4: 4-wave workgroups, two per CU (68 KB of LDS each)
-    const int form_b = (g_shade_variant & 32) ? (2 | (((g_shade_experiment >> 12) & 7) << 8)) : (g_shade_variant & 16) ? 1 : 0;
+    const int form_b = (g_shade_variant & 32) ? 2 : (g_shade_variant & 16) ? 1 : 0;
     if (!form_b && n_parts > 256) n_parts = 256;           // else: one 8-wave workgroup per CU (141 KB of LDS)
     const int rc = dvgo_shade_wgrad_x3(G1, gz, masks, W3, H1, H2, feat, C, emb, E, ray_id, M, m_dev, width, diffuse, n_parts, part,
                                        form_b, stream);

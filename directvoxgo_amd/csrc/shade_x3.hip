@@ -882,7 +882,7 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 #define X3C_PART(W) ((W) * (W) + (W) * 64 + 32 * (W) + 3 * (W))
 
-template <int WIDTH, int EXP = 0>                      // EXP: switch-off experiments (1: no MFMAs, 2: no re-requests, 4: no H1 splits)
+template <int WIDTH, int EXP = 0>                      // EXP: switch-off experiments of round 3 (1: no MFMAs, 2: no re-requests, 4: no H1 splits; profiles/r3/wgrad_c2_switch_off.txt)
 __global__ void __launch_bounds__(WIDTH * 2, 2)       // T waves; two workgroups per CU
 shade_wgrad_c2_kernel(const float* __restrict__ gz, const unsigned int* __restrict__ masks, const float* __restrict__ W3,
                       const float* __restrict__ H1, const float* __restrict__ H2, int64_t M_cap,
@@ -1291,16 +1291,10 @@ int dvgo_shade_wgrad_x3(const float* G1, const float* gz, const uint64_t* masks,
   const int c_view0 = diffuse ? 3 : 0;
   const int n_view = C - c_view0;
   if ((width != 128 && width != 64) || n_view < 0 || n_view + E > 40) return DVGO_ERANGE;
-  if ((form_b & 255) == 2) {
+  if (form_b == 2) {
     // no LDS, no barriers: 32-bit byte offsets everywhere
     if (M * width * 4 >= ((int64_t)1 << 32) || M * C * 4 >= ((int64_t)1 << 32) || M * 32 >= ((int64_t)1 << 32)) return DVGO_ERANGE;
-    const int exp = form_b >> 8;
-    if (width == 128 && exp) {
-#define X3C_EXP(E) case E: shade_wgrad_c2_kernel<128, E><<<n_parts, 256, 0, (hipStream_t)stream>>>(gz, (const unsigned int*)masks, W3, H1, H2, M, m_dev, part); break;
-      switch (exp) { X3C_EXP(1) X3C_EXP(2) X3C_EXP(3) X3C_EXP(4) X3C_EXP(5) X3C_EXP(6) X3C_EXP(7) }
-#undef X3C_EXP
-      shade_wgrad_c1_kernel<128><<<n_parts, 256, 0, (hipStream_t)stream>>>(G1, feat, C, c_view0, n_view, emb, E, ray_id, M, m_dev, part);
-    } else if (width == 128) {
+    if (width == 128) {
       shade_wgrad_c2_kernel<128><<<n_parts, 256, 0, (hipStream_t)stream>>>(gz, (const unsigned int*)masks, W3, H1, H2, M, m_dev, part);
       shade_wgrad_c1_kernel<128><<<n_parts, 256, 0, (hipStream_t)stream>>>(G1, feat, C, c_view0, n_view, emb, E, ray_id, M, m_dev, part);
     } else {

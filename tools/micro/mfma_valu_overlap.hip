@@ -7,7 +7,7 @@
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
 #define VALU4 "v_cvt_pk_bf16_f32 %4, %6, %7\n\tv_lshlrev_b32 %5, 16, %4\n\tv_and_b32 %4, 0xffff0000, %4\n\tv_sub_f32 %6, %6, %5\n\t"
-#define VALU2 "v_sub_f32 %7, %7, %4\n\tv_cvt_pk_bf16_f32 %5, %6, %7\n\t"
+#define VALU2B "v_sub_f32 %3, %3, %0\n\tv_cvt_pk_bf16_f32 %1, %2, %3\n\t"
 template <int K>
 __global__ void k(float* out, int iters) {
   f32x16 a, b;
@@ -17,13 +17,13 @@ __global__ void k(float* out, int iters) {
   float x = 1.5f + threadIdx.x, y = 0.25f;
   for (int it = 0; it < iters; ++it) {
 #define STEP(ACC)                                                                                                         \
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, %3, %0\n\t" : "+v"(ACC), "+v"(b) : "v"(fa), "v"(fb));                     \
-    if (K >= 2) asm volatile(VALU2 : "+v"(a), "+v"(b), "+v"(fa), "+v"(fb), "+v"(t0), "+v"(t1), "+v"(x), "+v"(y));            \
-    if (K >= 4) asm volatile(VALU2 : "+v"(a), "+v"(b), "+v"(fa), "+v"(fb), "+v"(t0), "+v"(t1), "+v"(x), "+v"(y));            \
-    if (K >= 6) asm volatile(VALU2 : "+v"(a), "+v"(b), "+v"(fa), "+v"(fb), "+v"(t0), "+v"(t1), "+v"(x), "+v"(y));            \
-    if (K >= 8) asm volatile(VALU2 : "+v"(a), "+v"(b), "+v"(fa), "+v"(fb), "+v"(t0), "+v"(t1), "+v"(x), "+v"(y));            \
-    if (K >= 10) asm volatile(VALU2 : "+v"(a), "+v"(b), "+v"(fa), "+v"(fb), "+v"(t0), "+v"(t1), "+v"(x), "+v"(y));           \
-    if (K >= 12) asm volatile(VALU2 : "+v"(a), "+v"(b), "+v"(fa), "+v"(fb), "+v"(t0), "+v"(t1), "+v"(x), "+v"(y));
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n\t" : "+v"(ACC) : "v"(fa), "v"(fb));                               \
+    if (K >= 2) asm volatile(VALU2B : "+v"(t0), "+v"(t1), "+v"(x), "+v"(y));            \
+    if (K >= 4) asm volatile(VALU2B : "+v"(t0), "+v"(t1), "+v"(x), "+v"(y));            \
+    if (K >= 6) asm volatile(VALU2B : "+v"(t0), "+v"(t1), "+v"(x), "+v"(y));            \
+    if (K >= 8) asm volatile(VALU2B : "+v"(t0), "+v"(t1), "+v"(x), "+v"(y));            \
+    if (K >= 10) asm volatile(VALU2B : "+v"(t0), "+v"(t1), "+v"(x), "+v"(y));           \
+    if (K >= 12) asm volatile(VALU2B : "+v"(t0), "+v"(t1), "+v"(x), "+v"(y));
     STEP(a) STEP(b) STEP(a) STEP(b) STEP(a) STEP(b) STEP(a) STEP(b) STEP(a) STEP(b) STEP(a) STEP(b)
   }
   float s = x + y + __uint_as_float(t0) + __uint_as_float(t1);
