@@ -522,8 +522,9 @@ def main():
     variant = L_.lib().dvgo_shade_variant(-1)
     out['config']['colour_head'] = ('fp32 operands split exactly into 3 bf16 pieces, 6 partial products per k-step on '
                                     'v_mfma_f32_32x32x16_bf16, fp32 accumulation -- fp32-grade results, held to the same '
-                                    'tolerances as the f32-MFMA kernels (tests/test_gpu_ops.py); weight gradients on '
-                                    'v_mfma_f32_32x32x2_f32') if (variant & 3) else 'v_mfma_f32_32x32x2_f32 throughout'
+                                    'tolerances as the f32-MFMA kernels (tests/test_gpu_ops.py); weight gradients '
+                                    + ('the same way (LDS-DMA ring, B fragments shared through LDS)' if (variant & 64)
+                                       else 'on v_mfma_f32_32x32x2_f32')) if (variant & 3) else 'v_mfma_f32_32x32x2_f32 throughout'
     if rank == 0 and world == 1 and not args.no_secondary and args.workload == 'roofline' and (variant & 3):
         # the same step with the colour head entirely on the f32 MFMA (round 1's kernels), for reference
         L_.lib().dvgo_shade_variant(0)

@@ -22,7 +22,8 @@ ENTRY = [   # kernel-name fragment -> C-ABI entry point (first match wins)
     ('march_composite_kernel', 'dvgo_march_composite'), ('march_feat_bwd', 'dvgo_march_feat_bwd'),
     ('grid_grad_split_kernel', 'dvgo_grid_grad_split'), ('shade_fwd_kernel', 'dvgo_shade_fwd'), ('shade_fwd_x3_kernel', 'dvgo_shade_fwd'),
     ('shade_bwd_kernel', 'dvgo_shade_bwd'), ('shade_bwd_x3_kernel', 'dvgo_shade_bwd'), ('shade_wgrad_kernel', 'dvgo_shade_wgrad'),
-    ('shade_wgrad_ring_kernel', 'dvgo_shade_wgrad'), ('shade_wgrad_x3_kernel', 'dvgo_shade_wgrad'), ('adam_rows_kernel', 'dvgo_adam_rows'),
+    ('shade_wgrad_ring_kernel', 'dvgo_shade_wgrad'), ('shade_wgrad_ring_x3_kernel', 'dvgo_shade_wgrad'), ('shade_wgrad_x3_kernel', 'dvgo_shade_wgrad'),
+    ('shade_wgrad_x3b_kernel', 'dvgo_shade_wgrad'), ('shade_wgrad_c1_kernel', 'dvgo_shade_wgrad'), ('shade_wgrad_c2_kernel', 'dvgo_shade_wgrad'), ('adam_rows_kernel', 'dvgo_adam_rows'),
     ('adam_kernel', 'dvgo_adam_upd'),
     ('ray_setup_kernel', 'dvgo_sample_pts_prepare'), ('march_scans_kernel', 'dvgo_march_scans'),
     ('brick_scan_kernel', 'dvgo_brick_scan'), ('brick_accumulate_kernel', 'dvgo_brick_accumulate'),
