@@ -913,11 +913,16 @@ shade_wgrad_ring_x3_kernel(const float* __restrict__ G1, const float* __restrict
   using Ring = ShadeWgradRingX3<WIDTH>;
   constexpr int T = WIDTH / 32, NW = T, NB = Ring::NB, NR = Ring::NR, TR = Ring::TR;
   static_assert(T == 4 || T == 2, "widths 128 and 64");
-  constexpr int LPR = WIDTH / 4, RPI = 64 / LPR, IPW = TR / RPI / NW, FPW = 4 / NW, EPW = 8 / NW;
+  constexpr int LPR = WIDTH / 4, RPI = 64 / LPR, IPW = TR / RPI / NW;
+  // The small requests (feature columns, embedding gather, gz, sign words, ray ids) are issued by the waves that do NOT
+  // split an X tile: at width 128 waves 2 and 3 (a request costs its wave ~90 cycles; waves 0 / 1 have ~500 cycles of X
+  // split the others would otherwise spend waiting at the second barrier).  DW = waves that issue them, dw = index among them.
+  constexpr int DW = NW == 4 ? 2 : NW, FPW = 4 / DW, EPW = 8 / DW;
   static_assert(IPW == 2 && NB == 2 && TR == 16, "double buffer of 16-row tiles: the wait at the top of a tile is vmcnt(0)");
   __shared__ __attribute__((aligned(16))) Ring L;
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, j = lane & 31;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int dw = NW == 4 ? w - 2 : w;
   f32x16 aW2[T], aW1[2];
   float vW3[3] = {0.0f, 0.0f, 0.0f}, sgz[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -950,12 +955,12 @@ shade_wgrad_ring_x3_kernel(const float* __restrict__ G1, const float* __restrict
   for (int i = 0; i < IPW; ++i) vo_bulk[i] = (unsigned)(((IPW * w + i) * RPI + lane / LPR) * WIDTH * 4 + 16 * (lane % LPR));
 #pragma unroll
   for (int i = 0; i < FPW; ++i) {
-    const int e = 64 * (w + NW * i) + lane, row = e >> 4, col = e & 15;
+    const int e = 64 * ((dw < 0 ? 0 : dw) + DW * i) + lane, row = e >> 4, col = e & 15;
     vo_f[i] = col < n_view ? (unsigned)((row * C + c_view0 + col) * 4) : DVGO_OOB;
   }
 #pragma unroll
   for (int i = 0; i < EPW; ++i) {
-    const int e = 64 * (w + NW * i) + lane, col = e & 31;
+    const int e = 64 * ((dw < 0 ? 0 : dw) + DW * i) + lane, col = e & 31;
     e_row[i] = e >> 5;
     vo_ecol[i] = col < E ? (unsigned)(col * 4) : DVGO_OOB;
   }
@@ -972,18 +977,19 @@ shade_wgrad_ring_x3_kernel(const float* __restrict__ G1, const float* __restrict
       __builtin_amdgcn_raw_ptr_buffer_load_lds(bH1, (dvgo_lptr_t)&L.h1[sl][rl][0], 16, vo_bulk[i], r0 * (WIDTH * 4), 0, 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(bH2, (dvgo_lptr_t)&L.h2[sl][rl][0], 16, vo_bulk[i], r0 * (WIDTH * 4), 0, 0);
     }
+    if (dw < 0) return;                 // (waves 0 / 1 at width 128: the bulk rows above were their whole share)
 #pragma unroll
     for (int i = 0; i < FPW; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(bF, (dvgo_lptr_t)(&L.xf[sl][0][0] + 64 * (w + NW * i)), 4, vo_f[i], r0 * (unsigned)(C * 4), 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(bF, (dvgo_lptr_t)(&L.xf[sl][0][0] + 64 * (dw + DW * i)), 4, vo_f[i], r0 * (unsigned)(C * 4), 0, 0);
     unsigned rids[EPW];
 #pragma unroll
     for (int i = 0; i < EPW; ++i) rids[i] = lds_u32<0>(lds_addr(&L.rid[t & (NR - 1)][e_row[i]]));
-    if constexpr (EPW == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rids[0]), "+v"(rids[1]));
-    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rids[0]), "+v"(rids[1]), "+v"(rids[EPW - 2]), "+v"(rids[EPW - 1]));
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rids[0]), "+v"(rids[1]), "+v"(rids[2]), "+v"(rids[3]));
 #pragma unroll
     for (int i = 0; i < EPW; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(bE, (dvgo_lptr_t)(&L.xe[sl][0][0] + 64 * (w + NW * i)), 4,
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(bE, (dvgo_lptr_t)(&L.xe[sl][0][0] + 64 * (dw + DW * i)), 4,
                                                vo_ecol[i] + rids[i] * (unsigned)(E * 4), 0, 0, 0);
+    // gz, the sign words and the ray ids of tile t + 2: one instruction each
     const unsigned rn = (unsigned)__builtin_amdgcn_readfirstlane(tile_of(t + 2) * TR);
     const int rsl = (t + 2) & (NR - 1);
     auto small = [&](int which) {
@@ -991,12 +997,7 @@ shade_wgrad_ring_x3_kernel(const float* __restrict__ G1, const float* __restrict
       else if (which == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(bM, (dvgo_lptr_t)&L.m2[sl][0][0], 4, vo_m2, r0 * 32u, 0, 0);
       else __builtin_amdgcn_raw_ptr_buffer_load_lds(bR, (dvgo_lptr_t)&L.rid[rsl][0], 4, vo_rid, rn * 8u, 0, 0);
     };
-    if constexpr (NW == 4) {
-      small(w < 2 ? w : 2);
-    } else {
-      small(w);
-      small(2);
-    }
+    if (dw == 0) { small(0); small(1); } else small(2);
   };
   // this lane's operand addresses in slot 0: its column, rows 8h .. 8h + 7 (the row enters as the immediate offset)
   const unsigned a_gz = lds_addr(&L.gz[0][8 * h][0]), a_mw = lds_addr(&L.m2[0][8 * h][m_idx]);
