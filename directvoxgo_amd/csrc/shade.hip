@@ -884,6 +884,15 @@ shade_wgrad_ring_kernel(const float* __restrict__ G1, const float* __restrict__ 
 //   * second barrier; 36 MFMAs per wave and tile (4 x 6 for dW2, 2 x 6 for dW1: the trailing X columns are a second
 //     MFMA tile here instead of 64 FMAs), fragments read from LDS two tiles at a time, MFMAs of two accumulators alternating.
 // ----------------------------------------------------------------------------------
+typedef float dvgo_f32x2 __attribute__((ext_vector_type(2)));
+// two dwords 256 * (O1 - O0) bytes apart with one LDS instruction (rows e and e + 1 of a column: a request costs its wave
+// ~10 cycles of issue, whatever its width)
+template <int O0, int O1> __device__ __forceinline__ dvgo_f32x2 lds_f32_pair_st64(unsigned a) {
+  dvgo_f32x2 v; asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(a), "n"(O0), "n"(O1)); return v;
+}
+template <int O0, int O1> __device__ __forceinline__ dvgo_f32x2 lds_f32_pair(unsigned a) {       // offsets in dwords
+  dvgo_f32x2 v; asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(a), "n"(O0), "n"(O1)); return v;
+}
 template <int OFF> __device__ __forceinline__ u32x4 lds_u32x4(unsigned a) {
   u32x4 v; asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF)); return v;
 }
@@ -1031,9 +1040,11 @@ shade_wgrad_ring_x3_kernel(const float* __restrict__ G1, const float* __restrict
     dvgo_f32x4 gq[8];
     unsigned mw[8];
     float g1v[8], h1v[8], h2v[8], xv[8];
-    static_for<0, 8>([&](auto Ec) {
-      constexpr int e = decltype(Ec)::value;
-      h1v[e] = lds_f32<e * WIDTH * 4>(b_h1);
+    constexpr int RS = WIDTH * 4 / 256;            // row stride in the 256-byte units of ds_read2st64
+    static_for<0, 4>([&](auto Ec) {
+      constexpr int e = 2 * decltype(Ec)::value;
+      const dvgo_f32x2 v = lds_f32_pair_st64<e * RS, (e + 1) * RS>(b_h1);
+      h1v[e] = v.x; h1v[e + 1] = v.y;
     });
     if (w < 2) {
       if (x_in_f) static_for<0, 8>([&](auto Ec) { constexpr int e = decltype(Ec)::value; xv[e] = lds_f32<e * 16 * 4>(b_x); });
@@ -1042,9 +1053,15 @@ shade_wgrad_ring_x3_kernel(const float* __restrict__ G1, const float* __restrict
     static_for<0, 8>([&](auto Ec) {
       constexpr int e = decltype(Ec)::value;
       gq[e] = lds_f32x4<16 * e>(b_gz);                 // broadcast
-      mw[e] = lds_u32<16 * e>(b_mw);
-      g1v[e] = lds_f32<e * WIDTH * 4>(b_g1);
-      h2v[e] = lds_f32<e * WIDTH * 4>(b_h2);
+    });
+    static_for<0, 4>([&](auto Ec) {
+      constexpr int e = 2 * decltype(Ec)::value;
+      const dvgo_f32x2 m = lds_f32_pair<4 * e, 4 * (e + 1)>(b_mw);
+      mw[e] = __float_as_uint(m.x); mw[e + 1] = __float_as_uint(m.y);
+      const dvgo_f32x2 a = lds_f32_pair_st64<e * RS, (e + 1) * RS>(b_g1);
+      g1v[e] = a.x; g1v[e + 1] = a.y;
+      const dvgo_f32x2 b = lds_f32_pair_st64<e * RS, (e + 1) * RS>(b_h2);
+      h2v[e] = b.x; h2v[e + 1] = b.y;
     });
     // the shared B fragments first: the other waves wait for them
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h1v[0]), "+v"(h1v[1]), "+v"(h1v[2]), "+v"(h1v[3]), "+v"(h1v[4]), "+v"(h1v[5]),
