@@ -17,7 +17,9 @@
 #include "common.h"
 #include "x3.h"
 
+#ifndef X3_THREADS
 #define X3_THREADS 512                 // 8 wavefronts: two per SIMD (<= 256 registers), one workgroup per CU (LDS)
+#endif
 #define X3_WAVES (X3_THREADS / 64)
 #define X3_STAGE_ROWS 16
 #define X3_STAGE_STRIDE 36
