@@ -21,6 +21,10 @@
 #define X3_THREADS 512                 // 8 wavefronts: two per SIMD (<= 256 registers), one workgroup per CU (LDS)
 #endif
 #define X3_WAVES (X3_THREADS / 64)
+#ifndef X3_BWD_THREADS
+#define X3_BWD_THREADS 512             // (768 = three waves per SIMD: fits the LDS, but 168 registers mean 70 B of scratch: 0.53 against 0.50 ms)
+#endif
+#define X3_BWD_WAVES (X3_BWD_THREADS / 64)
 #define X3_STAGE_ROWS 16
 #define X3_STAGE_STRIDE 36
 
@@ -286,7 +290,7 @@ struct X3BwdImg {
 
 template <int WIDTH>
 struct X3BwdLds : X3BwdImg<WIDTH> {
-  float stage[X3_WAVES][X3_STAGE_ROWS * X3_STAGE_STRIDE];
+  float stage[X3_BWD_WAVES][X3_STAGE_ROWS * X3_STAGE_STRIDE];
 };
 
 template <int WIDTH>
@@ -338,7 +342,7 @@ x3_prep_bwd_kernel(X3BwdImg<WIDTH>* __restrict__ Lp, const float* __restrict__ W
 }
 
 template <int WIDTH, bool DIFFUSE>
-__global__ void __launch_bounds__(X3_THREADS)
+__global__ void __launch_bounds__(X3_BWD_THREADS)
 shade_bwd_x3_kernel(const float* __restrict__ g_rgb, const float* __restrict__ rgb,
                     const unsigned long long* __restrict__ masks, int64_t M_cap, const int64_t* __restrict__ m_dev,
                     const void* __restrict__ image, int C, int c_view0,
@@ -1285,11 +1289,11 @@ int dvgo_shade_bwd_x3(const float* g_rgb, const float* rgb, const uint64_t* mask
   hipStream_t s = (hipStream_t)stream;
   const int64_t n_tiles = (M + 31) / 32;
   const int64_t cap = 256;
-  const int blocks = (int)((n_tiles + X3_WAVES - 1) / X3_WAVES < cap ? (n_tiles + X3_WAVES - 1) / X3_WAVES : cap);
+  const int blocks = (int)((n_tiles + X3_BWD_WAVES - 1) / X3_BWD_WAVES < cap ? (n_tiles + X3_BWD_WAVES - 1) / X3_BWD_WAVES : cap);
 #define DVGO_SHADE_BWD_X3(W, DIFF)                                                                                        \
   do {                                                                                                                    \
     if (!prebuilt) x3_prep_bwd_kernel<W><<<32, 256, 0, s>>>((X3BwdImg<W>*)scratch, W1, W2, W3, d_in);                   \
-    shade_bwd_x3_kernel<W, DIFF><<<blocks, X3_THREADS, 0, s>>>(g_rgb, rgb, (const unsigned long long*)masks, M, m_dev, scratch, C, \
+    shade_bwd_x3_kernel<W, DIFF><<<blocks, X3_BWD_THREADS, 0, s>>>(g_rgb, rgb, (const unsigned long long*)masks, M, m_dev, scratch, C, \
                                                                 c_view0, n_view, g_feat, G1, gz);                         \
   } while (0)
   if (width == 128) { if (diffuse) DVGO_SHADE_BWD_X3(128, true); else DVGO_SHADE_BWD_X3(128, false); }
